@@ -1,0 +1,101 @@
+"""Minimal graph container with the attribute surface the hot path touches.
+
+The reference moves ``torch_geometric.data.Data`` objects through the network
+(/root/reference/code/train_dual.py:201 ``d.to(device)``, :246 ``num_nodes``,
+/root/reference/code/net_util.py:158 ``Data(x, edge_index, ..)``).  Only attribute
+access, ``.to()``, ``num_nodes`` and ``hasattr`` semantics are needed on the path,
+so this is a plain attribute bag -- no PyG dependency.
+"""
+import torch
+
+
+class Data(object):
+    def __init__(self, x=None, edge_index=None, **kwargs):
+        self.x = x
+        self.edge_index = edge_index
+        # the reference relies on these reading as None when absent
+        # (net_util.py:81 ``data.pos``; :162 ``hasattr(data, 'edge_weight')``)
+        self.edge_weight = None
+        self.pos = None
+        self.y = None
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None and not k.startswith('_')]
+
+    @property
+    def num_nodes(self):
+        for k in ('x', 'pos', 'y'):
+            v = getattr(self, k, None)
+            if torch.is_tensor(v):
+                return v.shape[0]
+        if self.edge_index is not None and self.edge_index.numel() > 0:
+            return int(self.edge_index.max()) + 1
+        return 0
+
+    @property
+    def num_edges(self):
+        return 0 if self.edge_index is None else self.edge_index.shape[1]
+
+    def to(self, device, non_blocking=False):
+        out = Data()
+        for k, v in self.__dict__.items():
+            if k.startswith('_'):
+                continue
+            if torch.is_tensor(v):
+                v = v.to(device, non_blocking=non_blocking)
+            setattr(out, k, v)
+        return out
+
+    def clone(self):
+        out = Data()
+        for k, v in self.__dict__.items():
+            if k.startswith('_'):
+                continue
+            setattr(out, k, v.clone() if torch.is_tensor(v) else v)
+        return out
+
+    def __repr__(self):
+        parts = []
+        for k in self.keys():
+            v = getattr(self, k)
+            parts.append('%s=%s' % (k, list(v.shape) if torch.is_tensor(v) else repr(v)))
+        return 'Data(%s)' % ', '.join(parts)
+
+
+def union_batch(dual_list):
+    """Disjoint union of several (data_v, data_f) pairs into one pair.
+
+    Equivalent to the reference's gradient accumulation over ``batch_size``
+    sequential single-mesh steps (/root/reference/code/train_dual.py:211-218) when the
+    loss is averaged per mesh; pooling never links two components because graclus
+    only matches along edges.  ``mesh_ptr_v`` / ``mesh_ptr_f`` keep the per-mesh node
+    ranges so losses can be averaged per mesh.
+    """
+    xs_v, ys_v, ei_v, ew_v, dd_v = [], [], [], [], []
+    xs_f, ys_f, ei_f, ew_f, fv = [], [], [], [], []
+    ptr_v, ptr_f = [0], [0]
+    for dv, df in dual_list:
+        ov, of = ptr_v[-1], ptr_f[-1]
+        xs_v.append(dv.x); ei_v.append(dv.edge_index + ov); ew_v.append(dv.edge_weight)
+        xs_f.append(df.x); ei_f.append(df.edge_index + of); ew_f.append(df.edge_weight)
+        fv.append(df.fv_indices + ov)
+        if dv.y is not None:
+            ys_v.append(dv.y)
+        if df.y is not None:
+            ys_f.append(df.y)
+        if getattr(dv, 'depth_direction', None) is not None:
+            dd_v.append(dv.depth_direction)
+        ptr_v.append(ov + dv.x.shape[0])
+        ptr_f.append(of + df.x.shape[0])
+    # vertex graphs carry their self loops appended at the end (dataset.py:212-213);
+    # the union keeps each mesh's block contiguous, which the kernels do not rely on.
+    data_v = Data(torch.cat(xs_v), torch.cat(ei_v, 1), edge_weight=torch.cat(ew_v),
+                  y=torch.cat(ys_v) if ys_v else None,
+                  depth_direction=torch.cat(dd_v) if dd_v else None, name='union-v')
+    data_f = Data(torch.cat(xs_f), torch.cat(ei_f, 1), edge_weight=torch.cat(ew_f),
+                  y=torch.cat(ys_f) if ys_f else None, fv_indices=torch.cat(fv), name='union-f')
+    data_v.mesh_ptr = torch.tensor(ptr_v, dtype=torch.long)
+    data_f.mesh_ptr = torch.tensor(ptr_f, dtype=torch.long)
+    return data_v, data_f

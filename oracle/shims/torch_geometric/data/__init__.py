@@ -1,0 +1,12 @@
+"""TEST INFRASTRUCTURE (build container only) -- stand-in so the reference orchestration files can be
+imported by oracle/gen_golden.py.  NOT the real package: every symbol re-exports the restatement in
+oracle/pyg_ops.py, so results pinned through it cover the reference glue only, not these primitives."""
+from oracle.pyg_ops import Data  # noqa: F401
+
+
+class Batch(Data):
+    pass
+
+
+class Dataset(object):
+    pass

@@ -1,0 +1,115 @@
+"""CPU: the oracle restatement against the fixtures captured from the reference's own files
+(oracle/gen_golden.py).  Bit-exact at one thread; 1e-6 relative otherwise (CPU scatter
+backward is not deterministic across thread counts)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_fixture, fixture_dual_data, fixture_clusters, install_replay, rel_err
+from oracle import ref_model as R, pyg_ops as P
+from oracle.weights import make_state_dict, checksum
+
+
+@pytest.mark.parametrize('name', ['dualgnn_n4.npz', 'dualgnn_n11.npz', 'dualgnn_n4_depth.npz'])
+def test_dualgnn_matches_reference_glue(name):
+    fx = load_fixture(name)
+    torch.set_num_threads(1)
+    net = R.DualGNN(force_depth=bool(fx['force_depth']))
+    sd = make_state_dict(net.state_dict(), int(fx['weight_seed']))
+    assert abs(checksum(sd) - float(fx['weight_checksum'])) < 1e-6 * float(fx['weight_checksum'])
+    net.load_state_dict(sd)
+    install_replay(net, fixture_clusters(fx))
+    dv, df = fixture_dual_data(fx, P.Data)
+    vp, npred, _ = net((dv, df))
+    assert torch.equal(vp, torch.from_numpy(fx['out_verts']))
+    assert torch.equal(npred, torch.from_numpy(fx['out_normals']))
+    lv, ln = R.loss_v(vp, dv.y, 'L1'), R.loss_n(npred, df.y, 'L1')
+    loss = R.dual_loss(lv, ln)
+    assert loss.item() == float(fx['scalar_loss'])
+    assert R.error_n(npred, df.y).item() == float(fx['scalar_error_n'])
+    assert R.error_v(vp, dv.y).item() == float(fx['scalar_error_v'])
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert abs(p.grad.double().norm().item() - float(fx['gradnorm/' + k])) <= 1e-6 * float(fx['gradnorm/' + k]) + 1e-12, k
+        if 'grad/' + k in fx:
+            assert rel_err(p.grad, torch.from_numpy(fx['grad/' + k])) < 1e-6, k
+
+
+def test_graclus_reproduces_recorded_clusters():
+    """The seeded CPU greedy matching regenerates the clusters recorded from the reference run."""
+    fx = load_fixture('dualgnn_n4.npz')
+    torch.set_num_threads(1)
+    net = R.DualGNN()
+    net.load_state_dict(make_state_dict(net.state_dict(), int(fx['weight_seed'])))
+    dv, df = fixture_dual_data(fx, P.Data)
+    torch.manual_seed(1234)
+    net((dv, df))
+    raw = []
+    for m in (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2):
+        raw += m.last_clusters
+    for c, g in zip(raw, fixture_clusters(fx)):
+        assert torch.equal(c, g)
+
+
+def test_pure_functions():
+    fx = load_fixture('pure_functions.npz')
+    t = lambda k: torch.from_numpy(fx[k])
+    pts, fv, vf = t('points'), t('faces').long(), t('vf').long()
+    assert torch.equal(R.computer_face_normal(pts, fv), t('face_normal'))
+    from geobi_gnn_amd import meshgen
+    assert torch.equal(meshgen.calc_weight(pts, t('vnormal'), t('edge_index').long()), t('calc_weight'))
+    assert torch.equal(R.update_position2(pts, fv, vf, t('gt_normal'), n_iter=5), t('update2'))
+    assert torch.equal(R.update_position2(pts, fv, vf, t('gt_normal'), n_iter=3, depth_direction=t('depth_direction')),
+                       t('update2_depth'))
+    a, b = t('a'), t('b')
+    an, bn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(b, dim=1)
+    assert R.loss_v(a, b, 'L1').item() == float(fx['loss_v_L1'])
+    assert R.loss_v(a, b, 'L2').item() == float(fx['loss_v_L2'])
+    assert R.loss_n(an, bn, 'L1').item() == float(fx['loss_n_L1'])
+    assert R.loss_n(an, bn, 'L2').item() == float(fx['loss_n_L2'])
+    assert R.error_v(a, b).item() == float(fx['error_v'])
+    assert R.error_n(an, bn).item() == float(fx['error_n'])
+    assert float(R.dual_loss(torch.tensor(0.3), torch.tensor(0.9), 2.0, 0.5)) == float(fx['dual_loss'])
+    assert float(R.dual_loss(torch.tensor(0.3), torch.tensor(0.9), 2.0, 0.5, alpha=0.25)) == float(fx['dual_loss_alpha'])
+    pe_i, pe_w = R.pool_edge(t('cluster').long(), t('edge_index').long(), t('calc_weight'))
+    assert torch.equal(pe_i, t('pool_edge_index').long()) and torch.equal(pe_w, t('pool_edge_weight'))
+    assert torch.equal(R.pool_face(t('cluster').long(), fv), t('pool_face').long())
+
+
+def test_graclus_c_matches_python_loop():
+    torch.manual_seed(0)
+    n = 300
+    ei = torch.randint(0, n, (2, 3000))
+    ei = torch.cat([ei, ei.flip(0)], 1)
+    w = torch.rand(ei.shape[1])
+    perm = torch.randperm(n)
+    c_fast = P.graclus(ei, w, n, node_perm=perm)
+    saved, P._GRACLUS_C = P._GRACLUS_C, False
+    try:
+        c_slow = P.graclus(ei, w, n, node_perm=perm)
+    finally:
+        P._GRACLUS_C = saved
+    assert torch.equal(c_fast, c_slow)
+    # validity: clusters of size <= 2, pairs are edges, id = min(u, v)
+    cnt = torch.bincount(c_fast, minlength=n)
+    assert int(cnt.max()) <= 2
+    assert bool((c_fast <= torch.arange(n)).all())
+
+
+def test_feast_properties():
+    """Translation invariance of q and mean aggregation of a constant."""
+    torch.manual_seed(0)
+    conv = P.FeaStConv(5, 7, 9).double()
+    n = 40
+    ei = torch.randint(0, n, (2, 200))
+    x = torch.randn(n, 5, dtype=torch.double)
+    # constant features: every message equals sum_h q_h W_h x0, q = softmax(c) -> node independent
+    x0 = torch.randn(1, 5, dtype=torch.double).expand(n, 5)
+    out = conv(x0, ei)
+    assert torch.allclose(out, out[0:1].expand_as(out), atol=1e-12)
+    # permutation equivariance
+    perm = torch.randperm(n)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n)
+    out_a = conv(x, ei)
+    out_b = conv(x[perm], inv[ei])
+    assert torch.allclose(out_a[perm], out_b, atol=1e-10)
