@@ -1,0 +1,259 @@
+// extern "C" surface of libgeobi_hip.so (declared in include/geobi_hip.h): argument checks,
+// error reporting and the optional per-kernel event timing used by bench.py.
+#include "../../include/geobi_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace geobi {
+
+static thread_local char g_err[512] = "";
+
+int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+// ------------------------------------------------------------------------- profiling
+struct ProfRec {
+  hipEvent_t a, b;
+  double bytes;
+  int tag;
+};
+static int g_prof_kernel = PROF_NONE;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag) {
+  if (kernel != g_prof_kernel) return;
+  ProfRec r;
+  r.a = get_event();
+  r.b = get_event();
+  r.bytes = alg_bytes;
+  r.tag = tag;
+  if (!r.a || !r.b) return;
+  (void)hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+}
+
+void prof_end(int kernel, hipStream_t s) {
+  if (kernel != g_prof_kernel || g_prof.empty()) return;
+  (void)hipEventRecord(g_prof.back().b, s);
+}
+
+}  // namespace geobi
+
+using namespace geobi;
+
+#define S(stream) ((hipStream_t)(stream))
+#define NOTNULL(p)                                                       \
+  do {                                                                   \
+    if ((p) == nullptr) return set_error("%s: %s is NULL", __func__, #p); \
+  } while (0)
+
+extern "C" {
+
+int geobi_version(void) { return 100; }
+const char* geobi_last_error(void) { return g_err; }
+
+size_t geobi_csr_ws_bytes(int64_t E, int64_t N) { return csr_ws_bytes(E, N); }
+
+int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self,
+                       int32_t* rowptr, int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(rowptr);
+  if (E > 0) { NOTNULL(seg); NOTNULL(nbr); NOTNULL(col); NOTNULL(eid); }
+  return csr_from_coo(seg, nbr, E, N, drop_self, rowptr, col, eid, ws, ws_bytes, S(stream));
+}
+
+int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
+                        int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(rowptr); NOTNULL(rowptr_t);
+  if (Ecap > 0) { NOTNULL(col); NOTNULL(col_t); NOTNULL(pos_t); }
+  return csr_transpose(rowptr, col, N, Ecap, rowptr_t, col_t, pos_t, inv_pos, ws, ws_bytes, S(stream));
+}
+
+int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream) {
+  return expand_rowptr(rowptr, N, row, S(stream));
+}
+int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream) {
+  return gather_f32(src, idx, n, dst, S(stream));
+}
+
+int geobi_feast_ldz(int Cin) { return feast_ldz(Cin); }
+size_t geobi_feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) { return feast_fwd_ws_bytes(N, Cin, Cout); }
+
+static int check_channels(const char* fn, int Cin, int Cout) {
+  bool in_ok = Cin == 6 || Cin == 12 || Cin == 32 || Cin == 64 || Cin == 128;
+  bool out_ok = Cout == 32 || Cout == 64 || Cout == 128;
+  if (!in_ok || !out_ok) return set_error("%s: unsupported channels Cin=%d Cout=%d", fn, Cin, Cout);
+  return 0;
+}
+
+int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
+                    const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
+                    const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
+                    void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c); NOTNULL(bias);
+  NOTNULL(out); NOTNULL(p); NOTNULL(z);
+  if (Cb > 0) NOTNULL(xb);
+  if (E > 0) NOTNULL(col_in);
+  GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
+  return feast_fwd(xa, Cb > 0 ? xb : nullptr, Ca, Cb, N, E, rowptr_in, col_in, lin_w, u_w, c, bias, Cout, slope, out,
+                   p, z, ws, ws_bytes, S(stream));
+}
+
+size_t geobi_feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout) { return feast_bwd_ws_bytes(N, E, Cin, Cout); }
+
+int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
+                    const int32_t* rowptr_in, const int32_t* col_in, const int32_t* rowptr_out,
+                    const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
+                    const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
+                    const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc, float* dbias,
+                    void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(rowptr_out); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c);
+  NOTNULL(gout); NOTNULL(p); NOTNULL(z); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
+  if (slope != 1.0f) NOTNULL(out);
+  if (Cb > 0) { NOTNULL(xb); if (dxa) NOTNULL(dxb); }
+  if (E > 0) { NOTNULL(col_in); NOTNULL(col_out); NOTNULL(pos_in); }
+  GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
+  return feast_bwd(xa, Cb > 0 ? xb : nullptr, Ca, Cb, N, E, rowptr_in, col_in, rowptr_out, col_out, pos_in, lin_w,
+                   u_w, c, Cout, slope, out, gout, p, z, dxa, dxb, dlin_w, du_w, dc, dbias, ws, ws_bytes, S(stream));
+}
+
+int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,
+                          int64_t E, float* w_out, void* stream) {
+  if (E > 0) { NOTNULL(x); NOTNULL(row); NOTNULL(col); NOTNULL(w_out); }
+  return edge_weight_t10(x, C, row, col, w_in, E, w_out, S(stream));
+}
+
+size_t geobi_match_ws_bytes(int64_t N) { return match_ws_bytes(N); }
+int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
+                           int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(rowptr); NOTNULL(cluster); NOTNULL(status);
+  return match_heavy_edge(rowptr, col, w, N, rounds, cluster, status, ws, ws_bytes, S(stream));
+}
+
+size_t geobi_relabel_ws_bytes(int64_t N) { return relabel_ws_bytes(N); }
+int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws,
+                          size_t ws_bytes, void* stream) {
+  NOTNULL(cluster); NOTNULL(cnew); NOTNULL(count);
+  return relabel_compact(cluster, N, cnew, count, ws, ws_bytes, S(stream));
+}
+
+size_t geobi_segment_csr_ws_bytes(int64_t n) { return segment_csr_ws_bytes(n); }
+int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
+                      size_t ws_bytes, void* stream) {
+  NOTNULL(segptr);
+  return segment_csr(seg, n, nseg, segptr, members, ws, ws_bytes, S(stream));
+}
+int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
+                          float* out, int32_t* arg, void* stream) {
+  return segment_max_fwd(x, C, segptr, members, nseg, out, arg, S(stream));
+}
+int geobi_segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
+                          void* stream) {
+  return segment_max_bwd(gout, arg, C, nseg, n_fine, gx, S(stream));
+}
+int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
+                      float* out, void* stream) {
+  return segment_sum(x, C, segptr, members, nseg, mean, out, S(stream));
+}
+int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine,
+                           float* gx, void* stream) {
+  return segment_mean_bwd(gout, seg, segptr, C, n_fine, gx, S(stream));
+}
+int geobi_gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, void* stream) {
+  return gather_rows(x, idx, C, n_out, out, S(stream));
+}
+size_t geobi_pool_edge_ws_bytes(int64_t E) { return pool_edge_ws_bytes(E); }
+int geobi_pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E,
+                    int64_t nmax, int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
+                    void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(cnew); NOTNULL(rowptr_c); NOTNULL(count);
+  return pool_edge(cnew, row, col, w, E, nmax, rowptr_c, row_c, col_c, w_c, count, ws, ws_bytes, S(stream));
+}
+
+int geobi_face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
+                        void* stream) {
+  return face_geom_fwd(verts, fv, xf, ldxf, F, out, S(stream));
+}
+int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout, int64_t F, float* corner_grad,
+                        void* stream) {
+  return face_geom_bwd(verts, fv, gout, F, corner_grad, S(stream));
+}
+
+int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+                   const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
+                   int ld_resid, float* h, float* raw, float* out, void* stream) {
+  NOTNULL(x); NOTNULL(w1); NOTNULL(b1); NOTNULL(w2); NOTNULL(b2); NOTNULL(h); NOTNULL(raw); NOTNULL(out);
+  if (mode == 0) NOTNULL(resid);
+  return head_fwd(x, Cin, N, w1, b1, K, w2, b2, nout, slope, mode, dd, resid, ld_resid, h, raw, out, S(stream));
+}
+size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K) { return head_bwd_ws_bytes(N, Cin, K); }
+int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout,
+                   float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
+                   float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
+                   void* stream) {
+  NOTNULL(x); NOTNULL(w1); NOTNULL(w2); NOTNULL(h); NOTNULL(raw); NOTNULL(gout);
+  NOTNULL(dw1); NOTNULL(db1); NOTNULL(dw2); NOTNULL(db2);
+  return head_bwd(x, Cin, N, w1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, ws, ws_bytes,
+                  S(stream));
+}
+
+int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
+                  int K, const float* bias, float slope, void* stream) {
+  NOTNULL(A); NOTNULL(B); NOTNULL(C);
+  GemmEpilogue ep;
+  ep.bias = bias;
+  ep.slope = slope;
+  return gemm_nn(A, lda, B, ldb, transB, C, ldc, M, N, K, ep, S(stream));
+}
+size_t geobi_gemm_tn_ws_bytes(int I, int J, int64_t M) { return gemm_tn_ws_bytes(I, J, M); }
+int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc,
+                  void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(A); NOTNULL(B); NOTNULL(C);
+  return gemm_tn(A, lda, B, ldb, M, I, J, C, ldc, TN_PLAIN, 0, 0, ws, ws_bytes, S(stream));
+}
+
+int geobi_prof_enable(int kernel) {
+  // returns recorded events to the pool; callers collect before re-enabling
+  for (auto& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
+  g_prof.clear();
+  g_prof_kernel = kernel;
+  return 0;
+}
+
+int geobi_prof_collect(int tag, int64_t* launches, double* total_ms, double* total_bytes) {
+  NOTNULL(launches); NOTNULL(total_ms); NOTNULL(total_bytes);
+  *launches = 0; *total_ms = 0.0; *total_bytes = 0.0;
+  for (auto& r : g_prof) {
+    GEOBI_HIP(hipEventSynchronize(r.b));
+    if (tag != 0 && r.tag != tag) continue;
+    float ms = 0.f;
+    GEOBI_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    *launches += 1;
+    *total_ms += (double)ms;
+    *total_bytes += r.bytes;
+  }
+  return 0;
+}
+
+}  // extern "C"

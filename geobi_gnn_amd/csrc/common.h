@@ -1,0 +1,131 @@
+// Internal host/device helpers shared by the HIP translation units of libgeobi_hip.so.
+// gfx950 (MI355X) only: 64-lane wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define GEOBI_H 9    // FeaSt heads on the hot path (network.py:258-268 always passes 9)
+#define GEOBI_HP 12  // row stride (floats) of per-node / per-edge head vectors: 9 padded to 3 x float4
+
+namespace geobi {
+
+int set_error(const char* fmt, ...);
+
+#define GEOBI_HIP(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return ::geobi::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define GEOBI_LAUNCH_OK() GEOBI_HIP(hipGetLastError())
+#define GEOBI_TRY(expr)        \
+  do {                         \
+    int r_ = (expr);           \
+    if (r_ != 0) return r_;    \
+  } while (0)
+#define GEOBI_REQUIRE(cond, ...)                          \
+  do {                                                    \
+    if (!(cond)) return ::geobi::set_error(__VA_ARGS__);  \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// bump allocator over a caller-provided workspace (no hipMalloc on the hot path)
+struct Arena {
+  char* base;
+  size_t off, cap;
+  bool dry;  // dry run: only measure
+  Arena(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes), dry(p == nullptr) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t o = align_up(off);
+    off = o + n * sizeof(T);
+    if (dry) return nullptr;
+    return (off <= cap) ? (T*)(base + o) : nullptr;
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+// ---- optional per-kernel timing for bench.py's roofline object (events on the launch stream)
+enum ProfKernel { PROF_NONE = 0, PROF_AGG_FWD = 1, PROF_AGG_BWD = 2, PROF_ROWPASS = 3, PROF_GEMM = 4 };
+void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag);
+void prof_end(int kernel, hipStream_t s);
+
+// ---- launchers implemented across the translation units (all enqueue on `s`, never sync)
+// graph.hip
+size_t csr_ws_bytes(int64_t E, int64_t N);
+int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self, int32_t* rowptr,
+                 int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, hipStream_t s);
+int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
+                  int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, hipStream_t s);
+// gemm.hip
+struct GemmEpilogue {
+  const float* bias = nullptr;  // [N] added per column
+  float slope = 1.0f;           // leaky-relu negative slope (1 = identity)
+  float* C1 = nullptr;          // optional split output: columns >= split go to C1 (ld = ldc1)
+  int split = 0, ldc1 = 0;
+};
+int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
+            const GemmEpilogue& ep, hipStream_t s);
+size_t gemm_tn_ws_bytes(int I, int J, int64_t M);
+enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1 };
+int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc, int mode,
+            int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s);
+size_t colsum_ws_bytes(int64_t M, int J);
+int colsum(const float* A, int lda, int64_t M, int J, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+
+// feast.hip
+int feast_ldz(int Cin);
+size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
+int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
+              const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
+              int Cout, float slope, float* out, float* p, float* z, void* ws, size_t ws_bytes, hipStream_t s);
+size_t feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
+int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
+              const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
+              const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
+              const float* gout, const float* p, const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w,
+              float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+// pool.hip
+int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
+                    float* w_out, hipStream_t s);
+int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s);
+int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s);
+size_t match_ws_bytes(int64_t N);
+int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
+                     int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
+size_t relabel_ws_bytes(int64_t N);
+int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws, size_t ws_bytes,
+                    hipStream_t s);
+size_t segment_csr_ws_bytes(int64_t n);
+int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
+                size_t ws_bytes, hipStream_t s);
+int segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, float* out,
+                    int32_t* arg, hipStream_t s);
+int segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
+                    hipStream_t s);
+int segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
+                float* out, hipStream_t s);
+int segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine, float* gx,
+                     hipStream_t s);
+int gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, hipStream_t s);
+size_t pool_edge_ws_bytes(int64_t E);
+int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E, int64_t nmax,
+              int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, void* ws,
+              size_t ws_bytes, hipStream_t s);
+// geom.hip
+int face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
+                  hipStream_t s);
+int face_geom_bwd(const float* verts, const int32_t* fv, const float* g, int64_t F, float* corner_grad,
+                  hipStream_t s);
+int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+             const float* b2, int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid,
+             float* h, float* raw, float* out, hipStream_t s);
+size_t head_bwd_ws_bytes(int64_t N, int Cin, int K);
+int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout, float slope,
+             int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
+             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace geobi

@@ -1,0 +1,610 @@
+// FeaSt graph convolution (the 16 message-passing layers of the hot path), node-level form.
+//
+// Reference semantics (torch_geometric FeaStConv, called at /root/reference/code/network.py:271-299):
+//   q_ij = softmax_h(u (x_j - x_i) + c),  out_i = mean_{j in N(i) + self} sum_h q_ijh W_h x_j + bias.
+// The reference evaluates `lin(x_j)` per EDGE ([E, 9*Cout] temporaries).  Here
+//   p = x u^T                       per node   [N, 9]
+//   z_i[h,:] = 1/deg_i sum_j q_ijh x_j         (aggregation: the "scatter-add" of the path, done
+//                                               as a sorted-segment gather over the CSR -- no atomics)
+//   out = z W_packed + bias         per node   MFMA fp32 GEMM  [N, 9*Cin] x [9*Cin, Cout]
+// which needs Cin floats per edge instead of 9*Cout and keeps every sum in a fixed order.
+//
+// Backward (transposed aggregation instead of atomics):
+//   dz = g W_packed^T;  row pass over targets: s_ijh = dz_i[h,:].x_j, softmax backward -> dl_ij;
+//   column pass over sources j: r_j[h,:] = sum_i q_ijh/deg_i g_i  (same gather kernel, transposed CSR);
+//   dx = [r | dp] [lin.weight ; u.weight];  dW = z^T g;  du = dp^T x;  dc, dbias column sums.
+#include "common.h"
+
+namespace geobi {
+
+namespace {
+
+constexpr int H = GEOBI_H;
+constexpr int HP = GEOBI_HP;
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS ops of one wave execute in order; this only stops the compiler moving them across.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void softmax9(float (&l)[H]) {
+  float m = l[0];
+#pragma unroll
+  for (int h = 1; h < H; ++h) m = fmaxf(m, l[h]);
+  float s = 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    l[h] = expf(l[h] - m);
+    s += l[h];
+  }
+  float inv = 1.0f / s;
+#pragma unroll
+  for (int h = 0; h < H; ++h) l[h] *= inv;
+}
+
+__device__ __forceinline__ void load_hp(const float* __restrict__ row, float (&v)[H]) {
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+  float4 a = r4[0], b = r4[1], c = r4[2];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ ptr, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(ptr);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = ptr[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ ptr, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ptr[i] = v[i];
+  }
+}
+
+// ----------------------------------------------------------------------------- logits
+template <int C>
+__global__ __launch_bounds__(256) void feast_logits_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                           int Ca, const float* __restrict__ u, int N,
+                                                           float* __restrict__ p) {
+  __shared__ float su[H * C];
+  for (int i = threadIdx.x; i < H * C; i += 256) su[i] = u[i];
+  __syncthreads();
+  int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float acc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) acc[h] = 0.f;
+  const int Cb = C - Ca;
+  if constexpr ((C & 3) == 0) {
+    for (int k = 0; k < C; k += 4) {
+      const float* src = (k < Ca) ? xa + (size_t)n * Ca + k : xb + (size_t)n * Cb + (k - Ca);
+      float4 t = *reinterpret_cast<const float4*>(src);
+      float xv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = fmaf(xv[i], su[h * C + k + i], acc[h]);
+    }
+  } else {
+    for (int k = 0; k < C; ++k) {
+      float xv = (k < Ca) ? xa[(size_t)n * Ca + k] : xb[(size_t)n * Cb + (k - Ca)];
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc[h] = fmaf(xv, su[h * C + k], acc[h]);
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(p + (size_t)n * HP);
+  dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------- aggregation
+// G = C / VEC lanes own one centre node (VEC consecutive channels each); a wave owns 64 / G
+// consecutive nodes.  Per group and per chunk of G edges:
+//   phase 1 (lane = edge)   : gather p of the neighbour, 9-way softmax, park q and the neighbour
+//                             id in the wave's LDS slots -> every exp is computed exactly once;
+//   phase 2 (lane = channel): for each parked edge read q (LDS broadcast), gather the neighbour's
+//                             feature slice (VEC*4 B per lane, a row is one contiguous G*VEC*4 B
+//                             read) and fma into the 9 x VEC register accumulators.
+// MODE 0: forward  z_i[h,:] = 1/deg_i (q_self x_i + sum_j q_ij x_j),  logits p_j - p_i + c
+// MODE 1: backward transposed   r_j[h,:] = sum_i q_ij / deg_i g_i  (+ self), logits p_ctr - p_nbr + c,
+//         walking the CSR of the OTHER direction; deg comes from `deg_rowptr`.
+template <int C, int VEC, int MODE>
+__global__ __launch_bounds__(256) void feast_aggregate_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const int* __restrict__ deg_rowptr, int N, float* __restrict__ out, int ldo) {
+  constexpr int G = C / VEC;
+  constexpr int NPW = 64 / G;
+  static_assert(G * VEC == C && G >= 2 && (64 % G) == 0, "group shape");
+  __shared__ __attribute__((aligned(16))) float s_slot[4][64][HP];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / G, k = lane % G;
+  float(*slot)[HP] = s_slot[wave];
+  const int node0 = (blockIdx.x * 4 + wave) * NPW;
+  if (node0 >= N) return;
+  const int node = node0 + g;
+  const bool valid = node < N;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int re = valid ? rowptr[ns + 1] : rs;
+
+  const int c0 = k * VEC;
+  const float* fbase;
+  int fstride;
+  if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
+
+  float pc[H], cc[H], qs[H];
+  load_hp(p + (size_t)ns * HP, pc);
+#pragma unroll
+  for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
+  softmax9(qs);   // the self edge: u(x_i - x_i) + c = c exactly
+
+  float acc[H][VEC];
+  {
+    float xs[VEC];
+    load_vec<VEC>(fbase + (size_t)ns * fstride, xs);
+    float sscale = 1.0f;
+    if constexpr (MODE == 1) sscale = 1.0f / (float)(deg_rowptr[ns + 1] - deg_rowptr[ns] + 1);
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[h][v] = qs[h] * sscale * xs[v];
+  }
+
+  for (int base = rs; base < re; base += G) {
+    // ---- phase 1: lane k of the group handles edge base + k
+    {
+      const int e = base + k;
+      float q[H];
+      int j = ns;
+      if (e < re) {
+        j = col[e];
+        float pn[H];
+        load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = (MODE == 0) ? (pn[h] - pc[h] + cc[h]) : (pc[h] - pn[h] + cc[h]);
+        softmax9(q);
+        if constexpr (MODE == 1) {
+          float w = 1.0f / (float)(deg_rowptr[j + 1] - deg_rowptr[j] + 1);
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] *= w;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = 0.f;
+      }
+      float4* dst = reinterpret_cast<float4*>(slot[lane]);
+      dst[0] = make_float4(q[0], q[1], q[2], q[3]);
+      dst[1] = make_float4(q[4], q[5], q[6], q[7]);
+      dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
+    }
+    wave_lds_sync();
+    // ---- phase 2: all G lanes of the group walk the parked edges, two at a time
+    const int cnt = min(G, re - base);
+    for (int t = 0; t < cnt; t += 2) {
+      const float4* s0 = reinterpret_cast<const float4*>(slot[g * G + t]);
+      const float4* s1 = reinterpret_cast<const float4*>(slot[g * G + t + 1]);
+      float4 a0 = s0[0], b0 = s0[1], d0 = s0[2];
+      float4 a1 = s1[0], b1 = s1[1], d1 = s1[2];
+      float x0[VEC], x1[VEC];
+      load_vec<VEC>(fbase + (size_t)__float_as_int(d0.y) * fstride, x0);
+      load_vec<VEC>(fbase + (size_t)__float_as_int(d1.y) * fstride, x1);
+      const float q0[H] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x};
+      const float q1[H] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w, d1.x};
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[h][v] = fmaf(q0[h], x0[v], acc[h][v]);
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[h][v] = fmaf(q1[h], x1[v], acc[h][v]);
+    }
+    wave_lds_sync();
+  }
+
+  if (!valid) return;
+  float scale = 1.0f;
+  if constexpr (MODE == 0) scale = 1.0f / (float)(re - rs + 1);
+  float* orow = out + (size_t)node * ldo;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = acc[h][i] * scale;
+    store_vec<VEC>(orow + h * C + c0, v);
+  }
+  if constexpr (MODE == 0) {
+    // zero the row padding [H*C, ldo) so the packed GEMM can run over the padded K
+    for (int i = H * C + k; i < ldo; i += G) orow[i] = 0.f;
+  }
+}
+
+// --------------------------------------------------------------------- backward row pass
+template <int G>
+__device__ __forceinline__ float group_allreduce(float v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// For every target i (group of G lanes holding dz_i): per in-edge recompute q, form
+// s_h = dz_i[h,:].x_j, softmax backward dl_h = q_h (s_h - sum q s) / deg_i, write dl per edge
+// and the per-node sums:  dpn_i = sum_j dl_ij  (what flows to -p_i),  dcs_i = dpn_i + dl_self.
+template <int C, int VEC>
+__global__ __launch_bounds__(256) void feast_rowpass_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ dz, int ldz, int N, float* __restrict__ dl, float* __restrict__ dpn,
+    float* __restrict__ dcs) {
+  constexpr int G = C / VEC;
+  constexpr int NPW = 64 / G;
+  __shared__ __attribute__((aligned(16))) float s_slot[4][64][HP];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / G, k = lane % G;
+  float(*slot)[HP] = s_slot[wave];
+  const int node0 = (blockIdx.x * 4 + wave) * NPW;
+  if (node0 >= N) return;
+  const int node = node0 + g;
+  const bool valid = node < N;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int re = valid ? rowptr[ns + 1] : rs;
+
+  const int c0 = k * VEC;
+  const float* fbase;
+  int fstride;
+  if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
+
+  float pc[H], cc[H], qs[H];
+  load_hp(p + (size_t)ns * HP, pc);
+#pragma unroll
+  for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
+  softmax9(qs);
+
+  float dzr[H][VEC];
+#pragma unroll
+  for (int h = 0; h < H; ++h) load_vec<VEC>(dz + (size_t)ns * ldz + h * C + c0, dzr[h]);
+  const float invd = 1.0f / (float)(re - rs + 1);
+
+  float dsum[H];   // sum over real edges of dl
+  float dself[H];
+  {
+    float xs[VEC];
+    load_vec<VEC>(fbase + (size_t)ns * fstride, xs);
+    float s[H];
+    float tq = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float a = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xs[v], a);
+      s[h] = group_allreduce<G>(a);
+      tq = fmaf(qs[h], s[h], tq);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      dself[h] = qs[h] * (s[h] - tq) * invd;
+      dsum[h] = 0.f;
+    }
+  }
+
+  for (int base = rs; base < re; base += G) {
+    {
+      const int e = base + k;
+      float q[H];
+      int j = ns;
+      if (e < re) {
+        j = col[e];
+        float pn[H];
+        load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+        softmax9(q);
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = 0.f;
+      }
+      float4* dst = reinterpret_cast<float4*>(slot[lane]);
+      dst[0] = make_float4(q[0], q[1], q[2], q[3]);
+      dst[1] = make_float4(q[4], q[5], q[6], q[7]);
+      dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
+    }
+    wave_lds_sync();
+    const int cnt = min(G, re - base);
+    for (int t = 0; t < cnt; ++t) {
+      const float4* s0 = reinterpret_cast<const float4*>(slot[g * G + t]);
+      float4 a0 = s0[0], b0 = s0[1], d0 = s0[2];
+      float xj[VEC];
+      load_vec<VEC>(fbase + (size_t)__float_as_int(d0.y) * fstride, xj);
+      const float q[H] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x};
+      float s[H];
+      float tq = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xj[v], a);
+        s[h] = group_allreduce<G>(a);
+        tq = fmaf(q[h], s[h], tq);
+      }
+      float d[HP];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        d[h] = q[h] * (s[h] - tq) * invd;
+        dsum[h] += d[h];
+      }
+      d[9] = d[10] = d[11] = 0.f;
+      float4* drow = reinterpret_cast<float4*>(dl + (size_t)(base + t) * HP);
+#pragma unroll
+      for (int c4 = 0; c4 < 3; ++c4)
+        if (k == (c4 % G)) drow[c4] = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
+    }
+    wave_lds_sync();
+  }
+  if (!valid) return;
+  if (k == 0) {
+    float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
+    a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
+    a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
+    a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
+    float4* b = reinterpret_cast<float4*>(dcs + (size_t)node * HP);
+    b[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
+    b[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
+    b[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
+  }
+}
+
+// dp_j = sum over out-edges (j -> i) of dl_ij  -  dpn_j, written into the tail columns of r'
+__global__ void feast_dp_gather_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ pos_in,
+                                       const float* __restrict__ dl, const float* __restrict__ dpn, int N,
+                                       float* __restrict__ rp, int ldr, int col0) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = t / 3, q = t % 3;   // three float4 chunks per node
+  if (n >= N) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int rs = rowptr_out[n], re = rowptr_out[n + 1];
+  for (int e = rs; e < re; ++e) {
+    float4 v = reinterpret_cast<const float4*>(dl + (size_t)pos_in[e] * HP)[q];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4 m = reinterpret_cast<const float4*>(dpn + (size_t)n * HP)[q];
+  s.x -= m.x; s.y -= m.y; s.z -= m.z; s.w -= m.w;
+  reinterpret_cast<float4*>(rp + (size_t)n * ldr + col0)[q] = s;
+}
+
+// ------------------------------------------------------------------------- small helpers
+__global__ void pack_wf_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int Kp, float* __restrict__ wf) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Kp * Cout) return;
+  int kk = idx / Cout, o = idx % Cout;
+  int h = kk / Cin, k = kk % Cin;
+  wf[idx] = (h < H) ? lin_w[((size_t)h * Cout + o) * Cin + k] : 0.f;
+}
+
+__global__ void pack_wprime_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w, int Cin, int Cout,
+                                   int ldr, float* __restrict__ wp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ldr * Cin) return;
+  int r = idx / Cin, k = idx % Cin;
+  float v = 0.f;
+  if (r < H * Cout) v = lin_w[(size_t)r * Cin + k];
+  else if (r < H * Cout + H) v = u_w[(size_t)(r - H * Cout) * Cin + k];
+  wp[idx] = v;
+}
+
+__global__ void lrelu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out, float slope, int64_t n,
+                                 float* __restrict__ g) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g[i] = out[i] > 0.f ? gout[i] : gout[i] * slope;
+}
+
+template <int MODE>
+int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
+                     const int* rowptr, const int* col, const int* deg_rowptr, int N, float* out, int ldo,
+                     hipStream_t s) {
+#define GEOBI_AGG(C_, V_)                                                                                         \
+  do {                                                                                                            \
+    constexpr int NPW_ = 64 / (C_ / V_);                                                                          \
+    feast_aggregate_kernel<C_, V_, MODE><<<cdiv(N, 4 * NPW_), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col,     \
+                                                                            deg_rowptr, N, out, ldo);             \
+  } while (0)
+  switch (C) {
+    case 6: GEOBI_AGG(6, 3); break;
+    case 12: GEOBI_AGG(12, 3); break;
+    case 32: GEOBI_AGG(32, 4); break;
+    case 64: GEOBI_AGG(64, 4); break;
+    case 128: GEOBI_AGG(128, 4); break;
+    default: return set_error("feast: unsupported channel count %d (supported: 6, 12, 32, 64, 128)", C);
+  }
+#undef GEOBI_AGG
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
+                   const int* rowptr, const int* col, const float* dz, int ldz, int N, float* dl, float* dpn,
+                   float* dcs, hipStream_t s) {
+#define GEOBI_ROW(C_, V_)                                                                                     \
+  do {                                                                                                        \
+    constexpr int NPW_ = 64 / (C_ / V_);                                                                      \
+    feast_rowpass_kernel<C_, V_><<<cdiv(N, 4 * NPW_), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
+                                                                   N, dl, dpn, dcs);                          \
+  } while (0)
+  switch (C) {
+    case 6: GEOBI_ROW(6, 3); break;
+    case 12: GEOBI_ROW(12, 3); break;
+    case 32: GEOBI_ROW(32, 4); break;
+    case 64: GEOBI_ROW(64, 4); break;
+    case 128: GEOBI_ROW(128, 4); break;
+    default: return set_error("feast: unsupported channel count %d", C);
+  }
+#undef GEOBI_ROW
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int launch_logits(int C, const float* xa, const float* xb, int Ca, const float* u, int N, float* p, hipStream_t s) {
+  int blocks = cdiv(N, 256);
+  switch (C) {
+    case 6: feast_logits_kernel<6><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+    case 12: feast_logits_kernel<12><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+    case 32: feast_logits_kernel<32><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+    case 64: feast_logits_kernel<64><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+    case 128: feast_logits_kernel<128><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+    default: return set_error("feast: unsupported channel count %d", C);
+  }
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace
+
+int feast_ldz(int Cin) { return (H * Cin + 3) / 4 * 4; }
+int feast_ldr(int Cout) { return H * Cout + HP; }
+
+// algorithmic bytes of one aggregation launch (B_agg with z written out)
+double feast_agg_bytes(int64_t N, int64_t E, int C, int ld_out) {
+  return (double)E * (4.0 + 4.0 * C + 4.0 * H) + 4.0 * (double)N * H + 4.0 * (double)(N + 1) +
+         4.0 * (double)N * ld_out;
+}
+
+size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) {
+  (void)N;
+  return align_up((size_t)feast_ldz(Cin) * Cout * sizeof(float)) + 256;
+}
+
+int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
+              const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
+              int Cout, float slope, float* out, float* p, float* z, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int Cin = Ca + Cb;
+  GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_fwd: bad node count");
+  GEOBI_REQUIRE(Cb == 0 || Ca == Cb, "feast_fwd: a split input must have two equal halves");
+  const int Kp = feast_ldz(Cin);
+  Arena a(ws, ws_bytes);
+  float* wf = a.take<float>((size_t)Kp * Cout);
+  GEOBI_REQUIRE(a.ok() && wf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, wf);
+  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
+  prof_begin(PROF_AGG_FWD, s, feast_agg_bytes(N, Ecap, Cin, Kp), Cin);
+  int rc = launch_aggregate<0>(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, p, cvec, rowptr_in, col_in, nullptr, (int)N, z,
+                               Kp, s);
+  prof_end(PROF_AGG_FWD, s);
+  GEOBI_TRY(rc);
+  GemmEpilogue ep;
+  ep.bias = bias;
+  ep.slope = slope;
+  GEOBI_TRY(gemm_nn(z, Kp, wf, Cout, 0, out, Cout, (int)N, Cout, Kp, ep, s));
+  return 0;
+}
+
+struct BwdPlan {
+  size_t total;
+  float *g, *wf, *dz, *dl, *dpn, *dcs, *rp, *wp;
+  void *tn_ws, *cs_ws;
+  size_t tn_bytes, cs_bytes;
+};
+
+static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
+  const int Kp = feast_ldz(Cin), ldr = feast_ldr(Cout);
+  b.g = a.take<float>((size_t)N * Cout);
+  b.wf = a.take<float>((size_t)Kp * Cout);
+  b.dz = a.take<float>((size_t)N * Kp);
+  b.dl = a.take<float>((size_t)(Ecap > 0 ? Ecap : 1) * HP);
+  b.dpn = a.take<float>((size_t)N * HP);
+  b.dcs = a.take<float>((size_t)N * HP);
+  b.rp = a.take<float>((size_t)N * ldr);
+  b.wp = a.take<float>((size_t)ldr * Cin);
+  size_t t1 = gemm_tn_ws_bytes(Kp, Cout, N), t2 = gemm_tn_ws_bytes(H, Cin, N);
+  b.tn_bytes = t1 > t2 ? t1 : t2;
+  b.tn_ws = a.take<char>(b.tn_bytes);
+  b.cs_bytes = colsum_ws_bytes(N, Cout > HP ? Cout : HP);
+  b.cs_ws = a.take<char>(b.cs_bytes);
+  (void)need_dx;
+  b.total = align_up(a.off) + 256;
+}
+
+size_t feast_bwd_ws_bytes(int64_t N, int64_t Ecap, int Cin, int Cout) {
+  Arena a(nullptr, 0);
+  BwdPlan b;
+  plan_bwd(a, N, Ecap, Cin, Cout, true, b);
+  return b.total;
+}
+
+int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
+              const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
+              const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
+              const float* gout, const float* p, const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w,
+              float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int Cin = Ca + Cb;
+  const int Kp = feast_ldz(Cin), ldr = feast_ldr(Cout);
+  GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_bwd: bad node count");
+  Arena a(ws, ws_bytes);
+  BwdPlan b;
+  plan_bwd(a, N, Ecap, Cin, Cout, dxa != nullptr, b);
+  GEOBI_REQUIRE(a.ok() && ws, "feast_bwd: workspace too small (%zu < %zu)", ws_bytes, b.total);
+  const float* xb_ = xb ? xb : xa;
+  const int Ca_ = Cb ? Ca : Cin;
+
+  // 1. gradient through the fused leaky-relu
+  const float* g = gout;
+  if (slope != 1.0f) {
+    lrelu_bwd_kernel<<<cdiv(N * Cout, 256), 256, 0, s>>>(gout, out, slope, N * Cout, b.g);
+    GEOBI_LAUNCH_OK();
+    g = b.g;
+  }
+  // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
+  pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
+  GEOBI_LAUNCH_OK();
+  GemmEpilogue ep0;
+  GEOBI_TRY(gemm_nn(g, Cout, b.wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
+  // 3. row pass: per-edge softmax backward
+  prof_begin(PROF_ROWPASS, s, 0.0, Cin);
+  int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn, b.dcs, s);
+  prof_end(PROF_ROWPASS, s);
+  GEOBI_TRY(rc);
+  // 4. weight gradient dW = z^T g, unpacked into lin.weight layout
+  GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp, Cout, dlin_w, 0, TN_LIN_UNPACK, Cin, Cout, b.tn_ws, b.tn_bytes, s));
+  // 5. bias and c gradients
+  GEOBI_TRY(colsum(g, Cout, N, Cout, dbias, b.cs_ws, b.cs_bytes, s));
+  GEOBI_TRY(colsum(b.dcs, HP, N, H, dc, b.cs_ws, b.cs_bytes, s));
+  // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
+  feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, b.rp, ldr,
+                                                          H * Cout);
+  GEOBI_LAUNCH_OK();
+  if (dxa != nullptr) {
+    prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);
+    rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, s);
+    prof_end(PROF_AGG_BWD, s);
+    GEOBI_TRY(rc);
+    pack_wprime_kernel<<<cdiv((int64_t)ldr * Cin, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, ldr, b.wp);
+    GEOBI_LAUNCH_OK();
+    GemmEpilogue ep1;
+    if (Cb) { ep1.C1 = dxb; ep1.split = Ca; ep1.ldc1 = Cb; }
+    GEOBI_TRY(gemm_nn(b.rp, ldr, b.wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
+  }
+  // 7. du = dp^T x   (dp = r'[:, 9*Cout : 9*Cout+9])
+  GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, H, Ca_, du_w, Cin, TN_PLAIN, 0, 0, b.tn_ws, b.tn_bytes, s));
+  if (Cb)
+    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, H, Cb, du_w + Ca, Cin, TN_PLAIN, 0, 0, b.tn_ws, b.tn_bytes, s));
+  return 0;
+}
+
+}  // namespace geobi

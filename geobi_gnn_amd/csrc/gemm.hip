@@ -1,0 +1,374 @@
+// fp32 MFMA GEMMs for the dense per-node transforms of the FeaSt layers and the two heads.
+//
+// v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fma chain), which the 1e-5 parity bar
+// against the fp32 reference needs; there is no reduced-precision path.
+//   gemm_nn : C[M,N] = A[M,K] * B[K,N] (+bias, leaky-relu, optional column-split output)
+//             B may be given transposed ([N,K] row-major, e.g. nn.Linear.weight).
+//   gemm_tn : C[I,J] = sum_m A[m,I] * B[m,J]   (weight gradients; the reduction runs over the
+//             node dimension, split across workgroups into partial slabs that a second kernel
+//             adds in a fixed order -> deterministic, no float atomics).
+//   colsum  : column sums (bias / c gradients), same two-stage scheme.
+#include "common.h"
+
+namespace geobi {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;  // block rows
+constexpr int BK = 16;   // k-tile
+
+// A fragment for 32x32x2: lane l holds A[i = l & 31][k = l >> 5]; B fragment: B[k = l >> 5][j = l & 31].
+// C/D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb, int transB,
+                                                      float* __restrict__ C, int ldc, int M, int N, int K,
+                                                      const float* __restrict__ bias, float slope,
+                                                      float* __restrict__ C1, int split, int ldc1) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(WAVES_M * TM * 32 == BM, "block rows");
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int LDA_S = BM + 1;
+  constexpr int LDB_S = BN + 4;
+  __shared__ float As[BK][LDA_S];
+  __shared__ float Bs[BK][LDB_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool a_vec = ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool b_vec = ((ldb & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage A tile [BM x BK] transposed into As[k][m]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      int row = (tid >> 2) + pass * 64;
+      int kq = (tid & 3) * 4;
+      int gm = m0 + row, gk = k0 + kq;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (gm < M) {
+        const float* src = A + (size_t)gm * lda + gk;
+        if (a_vec && gk + 3 < K) {
+          float4 t = *reinterpret_cast<const float4*>(src);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (gk + i < K) v[i] = src[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[kq + i][row] = v[i];
+    }
+    // ---- stage B tile [BK x BN] into Bs[k][n]
+    if (!transB) {
+      constexpr int QPR = BN / 4;            // float4 per tile row
+      constexpr int TOTAL = BK * QPR;        // float4 per tile
+      for (int q = tid; q < TOTAL; q += 256) {
+        int kk = q / QPR, nq = (q % QPR) * 4;
+        int gk = k0 + kk, gn = n0 + nq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gk < K) {
+          const float* src = B + (size_t)gk * ldb + gn;
+          if (b_vec && gn + 3 < N) {
+            float4 t = *reinterpret_cast<const float4*>(src);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (gn + i < N) v[i] = src[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = v[i];
+      }
+    } else {
+      // B stored [N, K]: read along k, scatter transposed
+      constexpr int TOTAL = BN * (BK / 4);
+      for (int q = tid; q < TOTAL; q += 256) {
+        int nn = q >> 2, kq = (q & 3) * 4;
+        int gn = n0 + nn, gk = k0 + kq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gn < N) {
+          const float* src = B + (size_t)gn * ldb + gk;
+          if (b_vec && gk + 3 < K) {
+            float4 t = *reinterpret_cast<const float4*>(src);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (gk + i < K) v[i] = src[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = v[i];
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the k-tile
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+      const int kr = kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr][(wm * TM + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr][(wn * TN + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (col >= N) continue;
+      float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = acc[i][j][r] + bv;
+        v = v > 0.f ? v : v * slope;
+        if (C1 != nullptr && col >= split)
+          C1[(size_t)row * ldc1 + (col - split)] = v;
+        else
+          C[(size_t)row * ldc + col] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------ TN
+// Each wave owns a (32*TI) x (32*TJ) output tile and a slice of the reduction (node) range.
+// Operands are read straight from global memory in MFMA fragment order: for a k-step of two
+// consecutive nodes, lanes 0-31 read 32 consecutive floats of node m, lanes 32-63 of node m+1.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb, int64_t M, int I,
+                                                      int J, int tiles_j, int64_t m_per_slice,
+                                                      float* __restrict__ slabs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int ti = tile / tiles_j, tj = tile % tiles_j;
+  const int slice = blockIdx.y * 4 + wave;
+  const int64_t m_begin = (int64_t)slice * m_per_slice;
+  int64_t m_end = m_begin + m_per_slice;
+  if (m_end > M) m_end = M;
+  const int i0 = ti * 32 * TI, j0 = tj * 32 * TJ;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int64_t m = m_begin; m < m_end; m += 8) {
+    float av[4][TI], bv[4][TJ];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t mm = m + 2 * u + half;
+      bool ok = mm < m_end;
+#pragma unroll
+      for (int a = 0; a < TI; ++a) {
+        int ii = i0 + a * 32 + l31;
+        av[u][a] = (ok && ii < I) ? A[mm * lda + ii] : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) {
+        int jj = j0 + b * 32 + l31;
+        bv[u][b] = (ok && jj < J) ? B[mm * ldb + jj] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+  }
+  // partial slab [slice][I][J]
+  float* out = slabs + (size_t)slice * I * J;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      int jj = j0 + b * 32 + l31;
+      if (jj >= J) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int ii = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ii < I) out[(size_t)ii * J + jj] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, int I, int J, float* __restrict__ C,
+                                 int ldc, int mode, int Cin, int Cout) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= I * J) return;
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * I * J + idx];
+  int i = idx / J, j = idx % J;
+  if (mode == TN_PLAIN) {
+    C[(size_t)i * ldc + j] = s;
+  } else {
+    // rows are (head h, in-channel k) of the packed weight, columns are out-channels:
+    // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`)
+    int h = i / Cin, k = i % Cin;
+    if (h < GEOBI_H) C[((size_t)h * Cout + j) * Cin + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, int lda, int64_t M, int J,
+                                                             int64_t rows_per_block, float* __restrict__ partial) {
+  // block (bx, by) sums rows [bx*rpb, (bx+1)*rpb) of the column block by*cols .. ; the 256 threads
+  // form a (rows_par x cols) grid so narrow matrices (J = 9..32) still use the whole block.
+  __shared__ float red[256];
+  const int cols = J < 256 ? J : 256;
+  const int rows_par = 256 / cols;
+  const int rr = threadIdx.x / cols, jc = threadIdx.x % cols;
+  const int j = blockIdx.y * 256 + jc;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (rr < rows_par && j < J)
+    for (int64_t r = r0 + rr; r < r1; r += rows_par) s += A[r * lda + j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rr == 0 && j < J) {
+    float t = 0.f;
+    for (int q = 0; q < rows_par; ++q) t += red[q * cols + jc];
+    partial[(size_t)blockIdx.x * J + j] = t;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int blocks, int J, float* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * J + j];
+  out[j] = s;
+}
+
+struct TnPlan {
+  int ti, tj, tiles_i, tiles_j, slices, blocks_y;
+  int64_t m_per_slice;
+};
+
+TnPlan plan_tn(int I, int J, int64_t M) {
+  TnPlan p;
+  p.ti = 2;
+  p.tj = (J > 32) ? 2 : 1;
+  p.tiles_i = cdiv(I, 32 * p.ti);
+  p.tiles_j = cdiv(J, 32 * p.tj);
+  int tiles = p.tiles_i * p.tiles_j;
+  int64_t want = 4096 / (tiles > 0 ? tiles : 1);     // target ~4096 waves in flight
+  int64_t max_slices = (M + 255) / 256;              // >= 256 nodes per slice
+  int64_t sl = want < 4 ? 4 : want;
+  if (sl > max_slices) sl = max_slices;
+  if (sl < 1) sl = 1;
+  sl = (sl + 3) / 4 * 4;                             // 4 waves (slices) per block
+  p.slices = (int)sl;
+  p.blocks_y = p.slices / 4;
+  int64_t mps = (M + sl - 1) / sl;
+  p.m_per_slice = (mps + 7) / 8 * 8;
+  return p;
+}
+
+}  // namespace
+
+int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
+            const GemmEpilogue& ep, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  GEOBI_REQUIRE(K > 0, "gemm_nn: K must be positive");
+  dim3 block(256);
+#define GEOBI_GEMM_LAUNCH(WM, WN, TM_, TN_)                                                                       \
+  do {                                                                                                          \
+    constexpr int BN_ = WN * TN_ * 32;                                                                          \
+    dim3 grid(cdiv(M, BM), cdiv(N, BN_));                                                                       \
+    gemm_nn_kernel<WM, WN, TM_, TN_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K, ep.bias,   \
+                                                           ep.slope, ep.C1, ep.split, ep.ldc1);                 \
+  } while (0)
+  if (N > 64)
+    GEOBI_GEMM_LAUNCH(2, 2, 2, 2);
+  else if (N > 32)
+    GEOBI_GEMM_LAUNCH(2, 2, 2, 1);
+  else
+    GEOBI_GEMM_LAUNCH(4, 1, 1, 1);
+#undef GEOBI_GEMM_LAUNCH
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
+  TnPlan p = plan_tn(I, J, M);
+  return align_up((size_t)p.slices * I * J * sizeof(float)) + 256;
+}
+
+int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc, int mode,
+            int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (I <= 0 || J <= 0) return 0;
+  TnPlan p = plan_tn(I, J, M);
+  Arena a(ws, ws_bytes);
+  float* slabs = a.take<float>((size_t)p.slices * I * J);
+  GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
+  if (p.tj == 2)
+    gemm_tn_kernel<2, 2><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, p.tiles_j, p.m_per_slice, slabs);
+  else
+    gemm_tn_kernel<2, 1><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, p.tiles_j, p.m_per_slice, slabs);
+  GEOBI_LAUNCH_OK();
+  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.slices, I, J, C, ldc, mode, Cin, Cout);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+static int colsum_blocks(int64_t M) {
+  int64_t b = (M + 511) / 512;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+size_t colsum_ws_bytes(int64_t M, int J) { return align_up((size_t)colsum_blocks(M) * J * sizeof(float)) + 256; }
+
+int colsum(const float* A, int lda, int64_t M, int J, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (J <= 0) return 0;
+  int blocks = colsum_blocks(M);
+  Arena a(ws, ws_bytes);
+  float* partial = a.take<float>((size_t)blocks * J);
+  GEOBI_REQUIRE(a.ok() && partial, "colsum: workspace too small");
+  int64_t rpb = (M + blocks - 1) / blocks;
+  if (rpb < 1) rpb = 1;
+  colsum_partial_kernel<<<dim3(blocks, cdiv(J, 256)), 256, 0, s>>>(A, lda, M, J, rpb, partial);
+  GEOBI_LAUNCH_OK();
+  colsum_final_kernel<<<cdiv(J, 256), 256, 0, s>>>(partial, blocks, J, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace geobi

@@ -1,0 +1,240 @@
+// Geometry coupling between the two domains and the two regression heads.
+//
+//   face_geom   /root/reference/code/network.py:332-337 + data_util.py:182-198:
+//               x_f = cat(x_f[:, :6], centroid(pred. verts), unit normal(pred. verts));
+//               backward scatters into the vertices through vertex -> (face, corner) inverse
+//               lists (segment_sum in pool.hip), not atomics.
+//   head        network.py:324-343: Linear(32,1024) + leaky_relu(0.2) + Linear(1024, 1|3), then
+//               vertex head: (* depth_direction) + xyz;   face head: F.normalize(dim=1).
+#include "common.h"
+
+namespace geobi {
+
+namespace {
+
+constexpr float kNormEps = 1e-12f;   // torch.nn.functional.normalize default eps
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 mul(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__global__ void face_geom_fwd_kernel(const float* __restrict__ verts, const int* __restrict__ fv,
+                                     const float* __restrict__ xf, int ldxf, int F, float* __restrict__ out) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  V3 v0 = ld3(verts + 3 * (size_t)fv[3 * f]), v1 = ld3(verts + 3 * (size_t)fv[3 * f + 1]),
+     v2 = ld3(verts + 3 * (size_t)fv[3 * f + 2]);
+  V3 cen = add(add(v0, v1), v2);
+  cen = {cen.x / 3.0f, cen.y / 3.0f, cen.z / 3.0f};
+  V3 n = cross(sub(v1, v0), sub(v2, v0));
+  float len = fmaxf(sqrtf(dot(n, n)), kNormEps);
+  float* o = out + (size_t)f * 12;
+  const float* xi = xf + (size_t)f * ldxf;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o[c] = xi[c];
+  o[6] = cen.x; o[7] = cen.y; o[8] = cen.z;
+  o[9] = n.x / len; o[10] = n.y / len; o[11] = n.z / len;
+}
+
+// per-corner gradients cg[3f + corner][3] from g[f][6:12]
+__global__ void face_geom_bwd_kernel(const float* __restrict__ verts, const int* __restrict__ fv,
+                                     const float* __restrict__ g, int F, float* __restrict__ cg) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  V3 v0 = ld3(verts + 3 * (size_t)fv[3 * f]), v1 = ld3(verts + 3 * (size_t)fv[3 * f + 1]),
+     v2 = ld3(verts + 3 * (size_t)fv[3 * f + 2]);
+  const float* gr = g + (size_t)f * 12;
+  V3 gc = {gr[6] / 3.0f, gr[7] / 3.0f, gr[8] / 3.0f};
+  V3 gn = {gr[9], gr[10], gr[11]};
+  V3 a = sub(v1, v0), b = sub(v2, v0);
+  V3 n = cross(a, b);
+  float len = sqrtf(dot(n, n));
+  V3 dn;
+  if (len > kNormEps) {
+    V3 nh = mul(n, 1.0f / len);
+    dn = mul(sub(gn, mul(nh, dot(nh, gn))), 1.0f / len);
+  } else {
+    dn = mul(gn, 1.0f / kNormEps);   // clamped branch of normalize: n / eps
+  }
+  V3 da = cross(b, dn), db = cross(dn, a);   // d(a x b): da = b x dn, db = dn x a
+  V3 d1 = add(gc, da), d2 = add(gc, db), d0 = sub(sub(gc, da), db);
+  float* o = cg + (size_t)f * 9;
+  o[0] = d0.x; o[1] = d0.y; o[2] = d0.z;
+  o[3] = d1.x; o[4] = d1.y; o[5] = d1.z;
+  o[6] = d2.x; o[7] = d2.y; o[8] = d2.z;
+}
+
+// ------------------------------------------------------------------------------ heads
+// one wave per node: raw[c] = h[n,:] . W2[c,:] + b2[c]; then the head-specific finish.
+// mode 0 (vertex): out = raw (* dd) + resid      mode 1 (face): out = raw / max(|raw|, eps)
+template <int NOUT>
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ h, int K,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       int N, int mode, const float* __restrict__ dd,
+                                                       const float* __restrict__ resid, int ld_resid,
+                                                       float* __restrict__ raw, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float acc[NOUT];
+#pragma unroll
+  for (int c = 0; c < NOUT; ++c) acc[c] = 0.f;
+  const float* hr = h + (size_t)n * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    float4 hv = *reinterpret_cast<const float4*>(hr + k);
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) {
+      float4 wv = *reinterpret_cast<const float4*>(w2 + (size_t)c * K + k);
+      acc[c] = fmaf(hv.x, wv.x, acc[c]); acc[c] = fmaf(hv.y, wv.y, acc[c]);
+      acc[c] = fmaf(hv.z, wv.z, acc[c]); acc[c] = fmaf(hv.w, wv.w, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NOUT; ++c) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc[c] += __shfl_xor(acc[c], m, 64);
+    acc[c] += b2[c];
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int c = 0; c < NOUT; ++c) raw[(size_t)n * NOUT + c] = acc[c];
+  float o[3];
+  if (mode == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = (NOUT == 3) ? acc[c % NOUT] : acc[0] * dd[(size_t)n * 3 + c];
+      o[c] = v + resid[(size_t)n * ld_resid + c];
+    }
+  } else {
+    float len = fmaxf(sqrtf(acc[0] * acc[0] + acc[1 % NOUT] * acc[1 % NOUT] + acc[2 % NOUT] * acc[2 % NOUT]), kNormEps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = acc[c % NOUT] / len;
+  }
+  out[(size_t)n * 3] = o[0]; out[(size_t)n * 3 + 1] = o[1]; out[(size_t)n * 3 + 2] = o[2];
+}
+
+// gradient of the finish: graw from gout
+__global__ void head_finish_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ raw, int nout,
+                                       int mode, const float* __restrict__ dd, int N, float* __restrict__ graw) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* g = gout + (size_t)n * 3;
+  if (mode == 0) {
+    if (nout == 3) {
+      graw[(size_t)n * 3] = g[0]; graw[(size_t)n * 3 + 1] = g[1]; graw[(size_t)n * 3 + 2] = g[2];
+    } else {
+      const float* d = dd + (size_t)n * 3;
+      graw[n] = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+    }
+  } else {
+    const float* v = raw + (size_t)n * 3;
+    float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float* o = graw + (size_t)n * 3;
+    if (len > kNormEps) {
+      float inv = 1.0f / len;
+      float y0 = v[0] * inv, y1 = v[1] * inv, y2 = v[2] * inv;
+      float yg = y0 * g[0] + y1 * g[1] + y2 * g[2];
+      o[0] = (g[0] - y0 * yg) * inv; o[1] = (g[1] - y1 * yg) * inv; o[2] = (g[2] - y2 * yg) * inv;
+    } else {
+      o[0] = g[0] / kNormEps; o[1] = g[1] / kNormEps; o[2] = g[2] / kNormEps;
+    }
+  }
+}
+
+// dh[n,k] = (sum_c graw[n,c] W2[c,k]) * lrelu'(h[n,k])
+__global__ void head_dh_kernel(const float* __restrict__ graw, int nout, const float* __restrict__ w2,
+                               const float* __restrict__ h, int K, float slope, int64_t total,
+                               float* __restrict__ dh) {
+  int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (t >= total) return;
+  int64_t n = t / K;
+  int k = (int)(t % K);
+  float4 hv = *reinterpret_cast<const float4*>(h + t);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < nout; ++c) {
+    float gr = graw[n * nout + c];
+    float4 wv = *reinterpret_cast<const float4*>(w2 + (size_t)c * K + k);
+    s.x = fmaf(gr, wv.x, s.x); s.y = fmaf(gr, wv.y, s.y); s.z = fmaf(gr, wv.z, s.z); s.w = fmaf(gr, wv.w, s.w);
+  }
+  s.x = hv.x > 0.f ? s.x : s.x * slope; s.y = hv.y > 0.f ? s.y : s.y * slope;
+  s.z = hv.z > 0.f ? s.z : s.z * slope; s.w = hv.w > 0.f ? s.w : s.w * slope;
+  *reinterpret_cast<float4*>(dh + t) = s;
+}
+
+}  // namespace
+
+int face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
+                  hipStream_t s) {
+  if (F <= 0) return 0;
+  face_geom_fwd_kernel<<<cdiv(F, 256), 256, 0, s>>>(verts, fv, xf, ldxf, (int)F, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int face_geom_bwd(const float* verts, const int32_t* fv, const float* g, int64_t F, float* corner_grad,
+                  hipStream_t s) {
+  if (F <= 0) return 0;
+  face_geom_bwd_kernel<<<cdiv(F, 256), 256, 0, s>>>(verts, fv, g, (int)F, corner_grad);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+             const float* b2, int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid,
+             float* h, float* raw, float* out, hipStream_t s) {
+  GEOBI_REQUIRE(N > 0 && (K % 256) == 0 && (nout == 1 || nout == 3), "head_fwd: unsupported shape");
+  GEOBI_REQUIRE(!(mode == 0 && nout == 1 && dd == nullptr), "head_fwd: force_depth needs depth_direction");
+  GEOBI_REQUIRE(!(mode == 1 && nout != 3), "head_fwd: the face head has 3 outputs");
+  GemmEpilogue ep;
+  ep.bias = b1;
+  ep.slope = slope;
+  GEOBI_TRY(gemm_nn(x, Cin, w1, Cin, 1, h, K, (int)N, K, Cin, ep, s));
+  if (nout == 3)
+    head_out_kernel<3><<<cdiv(N, 4), 256, 0, s>>>(h, K, w2, b2, (int)N, mode, dd, resid, ld_resid, raw, out);
+  else
+    head_out_kernel<1><<<cdiv(N, 4), 256, 0, s>>>(h, K, w2, b2, (int)N, mode, dd, resid, ld_resid, raw, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t head_bwd_ws_bytes(int64_t N, int Cin, int K) {
+  size_t t1 = gemm_tn_ws_bytes(K, Cin, N), t2 = gemm_tn_ws_bytes(3, K, N);
+  size_t c = colsum_ws_bytes(N, K);
+  return align_up((size_t)N * 3 * sizeof(float)) + align_up((size_t)N * K * sizeof(float)) +
+         align_up(t1 > t2 ? t1 : t2) + align_up(c) + 1024;
+}
+
+int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout, float slope,
+             int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
+             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s) {
+  Arena a(ws, ws_bytes);
+  float* graw = a.take<float>((size_t)N * 3);
+  float* dh = a.take<float>((size_t)N * K);
+  size_t t1 = gemm_tn_ws_bytes(K, Cin, N), t2 = gemm_tn_ws_bytes(3, K, N);
+  size_t tnb = t1 > t2 ? t1 : t2;
+  void* tn_ws = a.take<char>(tnb);
+  size_t csb = colsum_ws_bytes(N, K);
+  void* cs_ws = a.take<char>(csb);
+  GEOBI_REQUIRE(a.ok() && ws, "head_bwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  head_finish_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(gout, raw, nout, mode, dd, (int)N, graw);
+  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(gemm_tn(graw, nout, h, K, N, nout, K, dw2, K, TN_PLAIN, 0, 0, tn_ws, tnb, s));
+  GEOBI_TRY(colsum(graw, nout, N, nout, db2, cs_ws, csb, s));
+  head_dh_kernel<<<cdiv(N * K / 4, 256), 256, 0, s>>>(graw, nout, w2, h, K, slope, N * K, dh);
+  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(gemm_tn(dh, K, x, Cin, N, K, Cin, dw1, Cin, TN_PLAIN, 0, 0, tn_ws, tnb, s));
+  GEOBI_TRY(colsum(dh, K, N, K, db1, cs_ws, csb, s));
+  if (dx) {
+    GemmEpilogue ep;
+    GEOBI_TRY(gemm_nn(dh, K, w1, Cin, 0, dx, Cin, (int)N, Cin, K, ep, s));
+  }
+  return 0;
+}
+
+}  // namespace geobi

@@ -1,0 +1,167 @@
+// Edge-sorted adjacency (CSR) construction for the mesh graphs.
+//
+// The reference hands the path COO `edge_index [2,E] int64` (row = source j, col = target i;
+// /root/reference/code/network.py:271 -> FeaStConv).  Every kernel of this library walks a
+// CSR sorted by (segment node, neighbour) so gathers are row-coalesced and aggregation is a
+// sorted-segment reduction (no atomics, fixed summation order -> bitwise reproducible).
+// Self loops are dropped here: FeaStConv removes and re-adds exactly one per node, which
+// the conv kernels apply implicitly, and the pooling layer drops them first too
+// (/root/reference/code/net_util.py:163).
+#include "common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace geobi {
+
+namespace {
+
+constexpr uint64_t kSentinel = ~0ull;
+
+__global__ void make_keys_kernel(const int64_t* __restrict__ seg, const int64_t* __restrict__ nbr, int64_t E,
+                                 int drop_self, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t a = seg[e], b = nbr[e];
+  keys[e] = (drop_self && a == b) ? kSentinel : (((uint64_t)a << 32) | (uint64_t)(uint32_t)b);
+  vals[e] = (int32_t)e;
+}
+
+__global__ void expand_keys_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int N,
+                                   int64_t Ecap, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  // one thread per node: emits (col << 32 | row) for its CSR segment
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) {
+    int rs = rowptr[n], re = rowptr[n + 1];
+    for (int e = rs; e < re; ++e) {
+      keys[e] = ((uint64_t)(uint32_t)col[e] << 32) | (uint64_t)(uint32_t)n;
+      vals[e] = e;
+    }
+  }
+  // tail [rowptr[N], Ecap) is padding
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)gridDim.x * blockDim.x;
+  int64_t E = rowptr[N];
+  for (int64_t e = E + t; e < Ecap; e += total) {
+    keys[e] = kSentinel;
+    vals[e] = -1;
+  }
+}
+
+__global__ void unpack_sorted_kernel(const uint64_t* __restrict__ keys, int64_t E, int32_t* __restrict__ col) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  uint64_t k = keys[e];
+  col[e] = (k == kSentinel) ? -1 : (int32_t)(uint32_t)(k & 0xffffffffu);
+}
+
+// rowptr[n] = first position whose key >= (n << 32)   (n = N gives the valid edge count)
+__global__ void rowptr_search_kernel(const uint64_t* __restrict__ keys, int64_t E, int N,
+                                     int32_t* __restrict__ rowptr) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  uint64_t target = (uint64_t)n << 32;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  rowptr[n] = (int32_t)lo;
+}
+
+__global__ void invert_perm_kernel(const int32_t* __restrict__ pos, int64_t Ecap, const int32_t* __restrict__ count,
+                                   int32_t* __restrict__ inv) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Ecap) return;
+  if (e < *count) inv[pos[e]] = (int32_t)e;
+}
+
+struct SortBuffers {
+  uint64_t *k_in, *k_out;
+  int32_t *v_in, *v_out;
+  void* temp;
+  size_t temp_bytes;
+};
+
+int carve_sort(Arena& a, int64_t E, SortBuffers& sb) {
+  size_t tb = 0;
+  if (E > 0) {
+    hipError_t err = rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
+                                               (int32_t*)nullptr, (size_t)E, 0u, 64u, (hipStream_t)0, false);
+    if (err != hipSuccess) return set_error("rocprim radix_sort size query failed: %s", hipGetErrorString(err));
+  }
+  sb.temp_bytes = tb;
+  sb.k_in = a.take<uint64_t>(E);
+  sb.k_out = a.take<uint64_t>(E);
+  sb.v_in = a.take<int32_t>(E);
+  sb.v_out = a.take<int32_t>(E);
+  sb.temp = a.take<char>(tb ? tb : 1);
+  return 0;
+}
+
+}  // namespace
+
+size_t csr_ws_bytes(int64_t E, int64_t N) {
+  (void)N;
+  Arena a(nullptr, 0);
+  SortBuffers sb;
+  if (carve_sort(a, E, sb) != 0) return 0;
+  return align_up(a.off) + 256;
+}
+
+int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self, int32_t* rowptr,
+                 int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "csr_from_coo: sizes out of int32 range");
+  if (E == 0) {
+    GEOBI_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (N + 1), s));
+    return 0;
+  }
+  Arena a(ws, ws_bytes);
+  SortBuffers sb;
+  GEOBI_TRY(carve_sort(a, E, sb));
+  GEOBI_REQUIRE(a.ok() && ws != nullptr, "csr_from_coo: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const int T = 256;
+  make_keys_kernel<<<cdiv(E, T), T, 0, s>>>(seg, nbr, E, drop_self, sb.k_in, sb.v_in);
+  GEOBI_LAUNCH_OK();
+  size_t tb = sb.temp_bytes;
+  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, eid, (size_t)E, 0u, 64u, s, false));
+  unpack_sorted_kernel<<<cdiv(E, T), T, 0, s>>>(sb.k_out, E, col);
+  GEOBI_LAUNCH_OK();
+  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, E, (int)N, rowptr);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+// Transposed CSR of a CSR whose valid edge count lives on the device (rowptr[N]); `Ecap` is the
+// allocated length of col.  pos_t[e_t] = position of that edge in the input CSR; inv_pos[e] =
+// position of input edge e in the transposed CSR.
+int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
+                  int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (Ecap == 0) {
+    GEOBI_HIP(hipMemsetAsync(rowptr_t, 0, sizeof(int32_t) * (N + 1), s));
+    return 0;
+  }
+  Arena a(ws, ws_bytes);
+  SortBuffers sb;
+  GEOBI_TRY(carve_sort(a, Ecap, sb));
+  GEOBI_REQUIRE(a.ok() && ws != nullptr, "csr_transpose: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const int T = 256;
+  int blocks = cdiv(N > 0 ? N : 1, T);
+  expand_keys_kernel<<<blocks, T, 0, s>>>(rowptr, col, (int)N, Ecap, sb.k_in, sb.v_in);
+  GEOBI_LAUNCH_OK();
+  size_t tb = sb.temp_bytes;
+  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, pos_t, (size_t)Ecap, 0u, 64u, s, false));
+  // low 32 bits of the transposed key hold the original row = the neighbour in the transposed view
+  unpack_sorted_kernel<<<cdiv(Ecap, T), T, 0, s>>>(sb.k_out, Ecap, col_t);
+  GEOBI_LAUNCH_OK();
+  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, Ecap, (int)N, rowptr_t);
+  GEOBI_LAUNCH_OK();
+  if (inv_pos) {
+    invert_perm_kernel<<<cdiv(Ecap, T), T, 0, s>>>(pos_t, Ecap, rowptr + N, inv_pos);
+    GEOBI_LAUNCH_OK();
+  }
+  return 0;
+}
+
+}  // namespace geobi

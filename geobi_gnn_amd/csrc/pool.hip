@@ -1,0 +1,468 @@
+// Graph pooling / unpooling kernels (PoolingLayer of the hot path,
+// /root/reference/code/net_util.py:56-245, and pool_edge :289-295).
+//
+//   edge_weight_t10   w_e += exp(-|x_i - x_j|^2 / 2)                       (net_util.py:226-230)
+//   match_*           heavy-edge matching, cluster id = min(u, v)          (graclus, net_util.py:127)
+//   relabel           dense ids by rank of the representative              (consecutive_cluster, :128)
+//   segment_csr       inverse lists  cluster -> members  (sorted, deterministic)
+//   segment_max/mean  feature pooling with arg-max for the backward        (scatter, :131-134)
+//   segment_sum       unpool backward (gather forward = `x[unpooling_indices]`, :242-245)
+//   pool_edge         relabel endpoints, drop loops, sort, merge duplicates by mean  (:289-295)
+//
+// Matching specification (deterministic, unlike torch_cluster's randomised orders): an edge is
+// taken iff it is the best remaining edge at BOTH endpoints under the total order
+// (weight desc, min(u,v) asc, max(u,v) asc) -- i.e. greedy matching in globally descending edge
+// order, computed by rounds of mutual proposals.  oracle/oracle_c.c:oracle_greedy_sorted is the
+// sequential statement of the same rule.
+#include "common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace geobi {
+
+namespace {
+
+constexpr uint64_t kSentinel = ~0ull;
+
+// ------------------------------------------------------------------------ edge weights
+// 8 lanes per edge, float4 per lane per pass.
+__global__ __launch_bounds__(256) void edge_weight_t10_kernel(const float* __restrict__ x, int C,
+                                                              const int* __restrict__ row,
+                                                              const int* __restrict__ col,
+                                                              const float* __restrict__ w_in, int64_t E,
+                                                              float* __restrict__ w_out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t e = t >> 3;
+  int l = (int)(t & 7);
+  bool ok = e < E;
+  int i = ok ? row[e] : 0, j = ok ? col[e] : 0;
+  float d = 0.f;
+  if (ok) {
+    const float* xi = x + (size_t)i * C;
+    const float* xj = x + (size_t)j * C;
+    if ((C & 3) == 0) {
+      for (int c = l * 4; c < C; c += 32) {
+        float4 a = *reinterpret_cast<const float4*>(xi + c);
+        float4 b = *reinterpret_cast<const float4*>(xj + c);
+        float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        d = fmaf(dx, dx, d); d = fmaf(dy, dy, d); d = fmaf(dz, dz, d); d = fmaf(dw, dw, d);
+      }
+    } else {
+      for (int c = l; c < C; c += 8) {
+        float dd = xi[c] - xj[c];
+        d = fmaf(dd, dd, d);
+      }
+    }
+  }
+  d += __shfl_xor(d, 1, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 4, 64);
+  if (ok && l == 0) w_out[e] = (w_in ? w_in[e] : 0.f) + expf(d * -0.5f);
+}
+
+// ---------------------------------------------------------------------------- matching
+__device__ __forceinline__ bool edge_better(float w1, int a1, int b1, float w2, int a2, int b2) {
+  // (a, b) = (min, max) endpoint ids
+  if (w1 != w2) return w1 > w2;
+  if (a1 != a2) return a1 < a2;
+  return b1 < b2;
+}
+
+__global__ void match_propose_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                     const float* __restrict__ w, const int* __restrict__ cluster, int N,
+                                     int* __restrict__ prop) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  if (cluster[u] >= 0) return;
+  int best = -1, ba = 0, bb = 0;
+  float bw = 0.f;
+  for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+    int v = col[e];
+    if (v == u || cluster[v] >= 0) continue;
+    float we = w ? w[e] : 1.0f;
+    int a = u < v ? u : v, b = u < v ? v : u;
+    if (best < 0 || edge_better(we, a, b, bw, ba, bb)) { best = v; bw = we; ba = a; bb = b; }
+  }
+  prop[u] = best;
+}
+
+__global__ void match_resolve_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
+                                     int* __restrict__ remaining) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  if (cluster[u] >= 0) return;
+  int v = prop[u];
+  if (v < 0) { cluster[u] = u; return; }          // no free neighbour left: singleton
+  if (prop[v] == u) cluster[u] = u < v ? u : v;   // mutual proposal: the pair is matched
+  else atomicAdd(remaining, 1);
+}
+
+__global__ void match_finish_kernel(int N, int* __restrict__ cluster) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < N && cluster[u] < 0) cluster[u] = u;
+}
+
+// ----------------------------------------------------------------------------- relabel
+__global__ void rep_flag_kernel(const int* __restrict__ cluster, int N, int* __restrict__ flag) {
+  // flag every id that occurs (benign race: all writers store 1); ids must lie in [0, N)
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < N) flag[cluster[u]] = 1;
+}
+
+__global__ void relabel_apply_kernel(const int* __restrict__ cluster, const int* __restrict__ flag,
+                                     const int* __restrict__ rank, int N, int* __restrict__ cnew,
+                                     int* __restrict__ count) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  cnew[u] = rank[cluster[u]];
+  if (u == N - 1) *count = rank[u] + flag[u];
+}
+
+// ------------------------------------------------------------------------ inverse lists
+__global__ void seg_keys_kernel(const int* __restrict__ seg, int64_t n, uint64_t* __restrict__ keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = ((uint64_t)(uint32_t)seg[i] << 32) | (uint64_t)(uint32_t)i;
+}
+
+__global__ void seg_unpack_kernel(const uint64_t* __restrict__ keys, int64_t n, int* __restrict__ members) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) members[i] = (int)(uint32_t)(keys[i] & 0xffffffffu);
+}
+
+__global__ void seg_ptr_kernel(const uint64_t* __restrict__ keys, int64_t n, int nseg, int* __restrict__ segptr) {
+  int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx > nseg) return;
+  uint64_t target = (uint64_t)sidx << 32;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  segptr[sidx] = (int)lo;
+}
+
+// ----------------------------------------------------------------------- segment reduce
+__global__ void segment_max_fwd_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr,
+                                       const int* __restrict__ members, int nseg, float* __restrict__ out,
+                                       int* __restrict__ arg) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nseg * C) return;
+  int sidx = (int)(t / C), c = (int)(t % C);
+  int rs = segptr[sidx], re = segptr[sidx + 1];
+  float best = 0.f;          // empty segment -> 0 (torch_scatter fills untouched rows with 0)
+  int bi = -1;
+  for (int e = rs; e < re; ++e) {
+    int m = members[e];      // members ascend, strict '>' keeps the first maximum
+    float v = x[(size_t)m * C + c];
+    if (bi < 0 || v > best) { best = v; bi = m; }
+  }
+  out[t] = best;
+  arg[t] = bi;
+}
+
+__global__ void segment_max_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg, int C,
+                                       int64_t total, float* __restrict__ gx) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int a = arg[t];
+  if (a >= 0) gx[(size_t)a * C + (t % C)] = gout[t];   // distinct (row, channel) per writer
+}
+
+__global__ void segment_sum_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr,
+                                   const int* __restrict__ members, int nseg, int mean, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nseg * C) return;
+  int sidx = (int)(t / C), c = (int)(t % C);
+  int rs = segptr[sidx], re = segptr[sidx + 1];
+  float s = 0.f;
+  for (int e = rs; e < re; ++e) s += x[(size_t)members[e] * C + c];
+  if (mean) s = s / (float)max(re - rs, 1);
+  out[t] = s;
+}
+
+__global__ void segment_mean_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ seg,
+                                        const int* __restrict__ segptr, int C, int64_t total,
+                                        float* __restrict__ gx) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int n = (int)(t / C), c = (int)(t % C);
+  int sidx = seg[n];
+  gx[t] = gout[(size_t)sidx * C + c] / (float)max(segptr[sidx + 1] - segptr[sidx], 1);
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, int C, int64_t total,
+                                   float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int n = (int)(t / C), c = (int)(t % C);
+  out[t] = x[(size_t)idx[n] * C + c];
+}
+
+// ---------------------------------------------------------------------------- pool_edge
+__global__ void pool_edge_keys_kernel(const int* __restrict__ cnew, const int* __restrict__ row,
+                                      const int* __restrict__ col, int64_t E, uint64_t* __restrict__ keys,
+                                      int* __restrict__ vals) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int a = cnew[row[e]], b = cnew[col[e]];
+  keys[e] = (a == b) ? kSentinel : (((uint64_t)(uint32_t)a << 32) | (uint64_t)(uint32_t)b);
+  vals[e] = (int)e;
+}
+
+__global__ void pool_edge_heads_kernel(const uint64_t* __restrict__ keys, int64_t E, int* __restrict__ head) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  uint64_t k = keys[e];
+  head[e] = (k != kSentinel && (e == 0 || keys[e - 1] != k)) ? 1 : 0;
+}
+
+__global__ void pool_edge_emit_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ vals,
+                                      const int* __restrict__ head, const int* __restrict__ rank,
+                                      const float* __restrict__ w, int64_t E, int* __restrict__ row_c,
+                                      int* __restrict__ col_c, float* __restrict__ w_c, uint64_t* __restrict__ ukeys,
+                                      int* __restrict__ count) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (e == E - 1) *count = rank[e] + head[e];
+  if (!head[e]) return;
+  uint64_t k = keys[e];
+  int o = rank[e];
+  row_c[o] = (int)(uint32_t)(k >> 32);
+  col_c[o] = (int)(uint32_t)(k & 0xffffffffu);
+  ukeys[o] = k;
+  if (w) {
+    // mean of the merged duplicates; fp64 accumulation makes the result independent of the
+    // order of the run, so w(a,b) == w(b,a) bit for bit and the matching stays symmetric
+    double s = 0.0;
+    int n = 0;
+    for (int64_t f = e; f < E && keys[f] == k; ++f) { s += (double)w[vals[f]]; ++n; }
+    w_c[o] = (float)(s / (double)n);
+  }
+}
+
+__global__ void pool_edge_rowptr_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ count, int nmax,
+                                        int* __restrict__ rowptr) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > nmax) return;
+  uint64_t target = (uint64_t)n << 32;
+  int lo = 0, hi = *count;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (ukeys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  rowptr[n] = lo;
+}
+
+__global__ void expand_rowptr_kernel(const int* __restrict__ rowptr, int N, int* __restrict__ row) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) row[e] = n;
+}
+
+__global__ void gather_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx, int64_t n,
+                                  float* __restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { int k = idx[i]; dst[i] = k >= 0 ? src[k] : 0.f; }
+}
+
+template <typename T>
+size_t scan_temp_bytes(int64_t n) {
+  size_t tb = 0;
+  (void)rocprim::exclusive_scan(nullptr, tb, (T*)nullptr, (T*)nullptr, (T)0, (size_t)n, rocprim::plus<T>(), (hipStream_t)0,
+                          false);
+  return tb;
+}
+
+size_t sort_keys_temp_bytes(int64_t n) {
+  size_t tb = 0;
+  (void)rocprim::radix_sort_keys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0,
+                           false);
+  return tb;
+}
+
+size_t sort_pairs_temp_bytes(int64_t n) {
+  size_t tb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr, (int*)nullptr,
+                            (size_t)n, 0u, 64u, (hipStream_t)0, false);
+  return tb;
+}
+
+}  // namespace
+
+int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
+                    float* w_out, hipStream_t s) {
+  if (E <= 0) return 0;
+  edge_weight_t10_kernel<<<cdiv(E * 8, 256), 256, 0, s>>>(x, C, row, col, w_in, E, w_out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s) {
+  if (n <= 0) return 0;
+  gather_f32_kernel<<<cdiv(n, 256), 256, 0, s>>>(src, idx, n, dst);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s) {
+  if (N <= 0) return 0;
+  expand_rowptr_kernel<<<cdiv(N, 256), 256, 0, s>>>(rowptr, (int)N, row);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t match_ws_bytes(int64_t N) { return align_up((size_t)N * sizeof(int)) + 512; }
+
+// `status[0]` receives the number of nodes still undecided after `rounds` rounds (0 = converged);
+// undecided nodes are closed as singletons so the clustering is always valid.
+int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
+                     int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(N > 0, "match: empty graph");
+  Arena a(ws, ws_bytes);
+  int* prop = a.take<int>(N);
+  GEOBI_REQUIRE(a.ok() && prop, "match: workspace too small");
+  GEOBI_HIP(hipMemsetAsync(cluster, 0xff, sizeof(int) * N, s));
+  int blocks = cdiv(N, 256);
+  for (int r = 0; r < rounds; ++r) {
+    GEOBI_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
+    match_propose_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, cluster, (int)N, prop);
+    match_resolve_kernel<<<blocks, 256, 0, s>>>(prop, (int)N, cluster, status);
+  }
+  GEOBI_LAUNCH_OK();
+  match_finish_kernel<<<blocks, 256, 0, s>>>((int)N, cluster);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t relabel_ws_bytes(int64_t N) {
+  return align_up((size_t)N * sizeof(int)) * 2 + align_up(scan_temp_bytes<int>(N)) + 512;
+}
+
+int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+  GEOBI_REQUIRE(N > 0, "relabel: empty");
+  Arena a(ws, ws_bytes);
+  int* flag = a.take<int>(N);
+  int* rank = a.take<int>(N);
+  size_t tb = scan_temp_bytes<int>(N);
+  void* temp = a.take<char>(tb ? tb : 1);
+  GEOBI_REQUIRE(a.ok() && flag, "relabel: workspace too small");
+  int blocks = cdiv(N, 256);
+  GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int) * N, s));
+  rep_flag_kernel<<<blocks, 256, 0, s>>>(cluster, (int)N, flag);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, flag, rank, 0, (size_t)N, rocprim::plus<int>(), s, false));
+  relabel_apply_kernel<<<blocks, 256, 0, s>>>(cluster, flag, rank, (int)N, cnew, count);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t segment_csr_ws_bytes(int64_t n) {
+  return align_up((size_t)n * sizeof(uint64_t)) * 2 + align_up(sort_keys_temp_bytes(n)) + 512;
+}
+
+int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
+                size_t ws_bytes, hipStream_t s) {
+  if (n <= 0) {
+    GEOBI_HIP(hipMemsetAsync(segptr, 0, sizeof(int) * (nseg + 1), s));
+    return 0;
+  }
+  Arena a(ws, ws_bytes);
+  uint64_t* k_in = a.take<uint64_t>(n);
+  uint64_t* k_out = a.take<uint64_t>(n);
+  size_t tb = sort_keys_temp_bytes(n);
+  void* temp = a.take<char>(tb ? tb : 1);
+  GEOBI_REQUIRE(a.ok() && k_in, "segment_csr: workspace too small");
+  seg_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(seg, n, k_in);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::radix_sort_keys(temp, tb, k_in, k_out, (size_t)n, 0u, 64u, s, false));
+  seg_unpack_kernel<<<cdiv(n, 256), 256, 0, s>>>(k_out, n, members);
+  seg_ptr_kernel<<<cdiv(nseg + 1, 256), 256, 0, s>>>(k_out, n, (int)nseg, segptr);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, float* out,
+                    int32_t* arg, hipStream_t s) {
+  if (nseg <= 0) return 0;
+  segment_max_fwd_kernel<<<cdiv(nseg * C, 256), 256, 0, s>>>(x, C, segptr, members, (int)nseg, out, arg);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
+                    hipStream_t s) {
+  GEOBI_HIP(hipMemsetAsync(gx, 0, sizeof(float) * n_fine * C, s));
+  if (nseg <= 0) return 0;
+  segment_max_bwd_kernel<<<cdiv(nseg * C, 256), 256, 0, s>>>(gout, arg, C, nseg * C, gx);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
+                float* out, hipStream_t s) {
+  if (nseg <= 0) return 0;
+  segment_sum_kernel<<<cdiv(nseg * C, 256), 256, 0, s>>>(x, C, segptr, members, (int)nseg, mean, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine, float* gx,
+                     hipStream_t s) {
+  if (n_fine <= 0) return 0;
+  segment_mean_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, seg, segptr, C, n_fine * C, gx);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, hipStream_t s) {
+  if (n_out <= 0) return 0;
+  gather_rows_kernel<<<cdiv(n_out * C, 256), 256, 0, s>>>(x, idx, C, n_out * C, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t pool_edge_ws_bytes(int64_t E) {
+  return align_up((size_t)E * sizeof(uint64_t)) * 3 + align_up((size_t)E * sizeof(int)) * 4 +
+         align_up(sort_pairs_temp_bytes(E)) + align_up(scan_temp_bytes<int>(E)) + 1024;
+}
+
+// Outputs are sized for the worst case (E entries, nmax + 1 row pointers); the true edge count is
+// written to count[0] on the device.
+int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E, int64_t nmax,
+              int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, void* ws,
+              size_t ws_bytes, hipStream_t s) {
+  if (E <= 0) {
+    GEOBI_HIP(hipMemsetAsync(rowptr_c, 0, sizeof(int) * (nmax + 1), s));
+    GEOBI_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    return 0;
+  }
+  Arena a(ws, ws_bytes);
+  uint64_t* k_in = a.take<uint64_t>(E);
+  uint64_t* k_out = a.take<uint64_t>(E);
+  uint64_t* ukeys = a.take<uint64_t>(E);
+  int* v_in = a.take<int>(E);
+  int* v_out = a.take<int>(E);
+  int* head = a.take<int>(E);
+  int* rank = a.take<int>(E);
+  size_t tb_sort = sort_pairs_temp_bytes(E), tb_scan = scan_temp_bytes<int>(E);
+  void* t_sort = a.take<char>(tb_sort ? tb_sort : 1);
+  void* t_scan = a.take<char>(tb_scan ? tb_scan : 1);
+  GEOBI_REQUIRE(a.ok() && k_in, "pool_edge: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  int blocks = cdiv(E, 256);
+  pool_edge_keys_kernel<<<blocks, 256, 0, s>>>(cnew, row, col, E, k_in, v_in);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::radix_sort_pairs(t_sort, tb_sort, k_in, k_out, v_in, v_out, (size_t)E, 0u, 64u, s, false));
+  pool_edge_heads_kernel<<<blocks, 256, 0, s>>>(k_out, E, head);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::exclusive_scan(t_scan, tb_scan, head, rank, 0, (size_t)E, rocprim::plus<int>(), s, false));
+  pool_edge_emit_kernel<<<blocks, 256, 0, s>>>(k_out, v_out, head, rank, w, E, row_c, col_c, w_c, ukeys, count);
+  GEOBI_LAUNCH_OK();
+  pool_edge_rowptr_kernel<<<cdiv(nmax + 1, 256), 256, 0, s>>>(ukeys, count, (int)nmax, rowptr_c);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace geobi

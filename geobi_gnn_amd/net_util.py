@@ -1,0 +1,287 @@
+"""Graph pooling / unpooling behind the reference's ``net_util`` surface.
+
+Mirrors /root/reference/code/net_util.py: ``PoolingLayer`` (:56-245), ``pool_edge`` (:289-295),
+``pool_face`` (:298-302), ``pooling`` (:305-343), ``pooling_pre`` (:346-366), ``pooling_run``
+(:369-380) -- same names, arguments and side effects (``unpooling_indices`` kept on the module,
+``data.edge_index`` / ``data.edge_weight`` rewritten loop-free).  The kernels are in
+libgeobi_hip.so; edge lists come back (row, col)-sorted, a permutation of the reference's order.
+
+Matching differs from torch_cluster by design: graclus visits nodes in a random order (CPU) or
+runs randomised propose/respond rounds (CUDA) and is not reproducible; the HIP matching is the
+deterministic greedy matching in descending edge-weight order (same objective, same
+``cluster = min(u, v)`` labelling).  ``PoolingLayer.graclus_fn`` lets a caller supply cluster
+vectors instead (parity tests replay the reference's recorded clusters through it).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .data import Data
+from .graph import Graph, graph_of, attach
+
+MATCH_ROUNDS = 24
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS):
+    """Heavy-edge matching on the out-CSR; returns (cluster int32 [N], status int32 [1])."""
+    dev = graph.device
+    cluster = torch.empty(graph.N, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = L.workspace(L.lib().geobi_match_ws_bytes(graph.N), dev)
+    w = None if weight_sorted is None else weight_sorted.contiguous()
+    L.call('geobi_match_heavy_edge', L.ptr(graph.rowptr_out), L.ptr(graph.col_out), L.ptr(w), graph.N, rounds,
+           L.ptr(cluster), L.ptr(status), L.ptr(ws), ws.numel(), L.stream())
+    return cluster, status
+
+
+def relabel(cluster32):
+    """consecutive_cluster: dense ids; returns (cnew int32 [N], count int32 [1] on device)."""
+    n = cluster32.shape[0]
+    dev = cluster32.device
+    cnew = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = L.workspace(L.lib().geobi_relabel_ws_bytes(n), dev)
+    L.call('geobi_relabel_compact', L.ptr(cluster32), n, L.ptr(cnew), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
+    return cnew, count
+
+
+def _pool_edge_raw(cnew32, graph, weight_sorted):
+    """pool_edge on the out-CSR; worst-case sized outputs + device edge count."""
+    dev = graph.device
+    E, nmax = graph.E, graph.N
+    cap = max(E, 1)
+    rowptr_c = torch.empty(nmax + 1, dtype=torch.int32, device=dev)
+    row_c = torch.empty(cap, dtype=torch.int32, device=dev)
+    col_c = torch.empty(cap, dtype=torch.int32, device=dev)
+    w_c = None if weight_sorted is None else torch.empty(cap, dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = L.workspace(L.lib().geobi_pool_edge_ws_bytes(E), dev)
+    L.call('geobi_pool_edge', L.ptr(cnew32), L.ptr(graph.ensure_rows()), L.ptr(graph.col_out),
+           L.ptr(None if weight_sorted is None else weight_sorted.contiguous()), E, nmax, L.ptr(rowptr_c),
+           L.ptr(row_c), L.ptr(col_c), L.ptr(w_c), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
+    return rowptr_c, row_c, col_c, w_c, count
+
+
+def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
+    """One pooling step on the structure: match (unless given) -> relabel -> pool_edge.
+
+    One host sync reads {undecided nodes, coarse node count, coarse edge count}.
+    Returns (cnew int32, coarse Graph, coarse weights, raw cluster int32)."""
+    status = None
+    if cluster32 is None:
+        cluster32, status = hip_match(graph, weight_sorted, rounds)
+        cnew, ncount = relabel(cluster32)
+        rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
+        undecided, nc, ec = torch.cat([status, ncount, ecount]).tolist()
+        if undecided:   # rare: proposal chains longer than `rounds`; redo with the bound lifted
+            return _coarsen(graph, weight_sorted, None, rounds * 4)
+    else:
+        cnew, ncount = relabel(cluster32)
+        rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
+        nc, ec = torch.cat([ncount, ecount]).tolist()
+    coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec])
+    return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32
+
+
+def _pool_features(x, sidx, pool_type):
+    return ops.SegmentMaxFn.apply(x, sidx) if pool_type == 'max' else ops.SegmentMeanFn.apply(x, sidx)
+
+
+def _compose(clusts):
+    clust = clusts[-1]
+    for c in clusts[-2::-1]:
+        clust = clust[c.long()]
+    return clust
+
+
+def _feature_gauss(x, graph, denom):
+    """exp(-|x_i - x_j|^2 / denom) per sorted edge (types 1, 2, 8, 9); type 10 has its own kernel."""
+    out = torch.empty(max(graph.E, 1), dtype=torch.float32, device=x.device)[:graph.E]
+    L.call('geobi_edge_weight_t10', L.ptr(x.detach().contiguous()), x.shape[1], L.ptr(graph.ensure_rows()),
+           L.ptr(graph.col_out), None, graph.E, L.ptr(out), L.stream())
+    return out if denom == 2 else out.pow(2.0 / denom)
+
+
+def _minmax(v):
+    return (v - v.min()) / (v.max() - v.min() + 1e-12)
+
+
+class PoolingLayer(nn.Module):
+    def __init__(self, in_channel, pool_type='max', pool_step=2, edge_weight_type=0, wei_param=2):
+        super().__init__()
+        assert pool_type in ['max', 'mean']
+        self.pool_type = pool_type
+        self.pool_step = pool_step
+        self.edge_weight_type = edge_weight_type
+        self.wei_param = wei_param
+        if self.edge_weight_type in [4, 5]:
+            self.lin = nn.Linear(in_channel, in_channel)
+        if self.edge_weight_type in [3, 4, 5]:
+            self.att_l = nn.Parameter(torch.empty(1, in_channel))
+            self.att_r = nn.Parameter(torch.empty(1, in_channel))
+            nn.init.xavier_uniform_(self.att_l.data, gain=1.414)
+            nn.init.xavier_uniform_(self.att_r.data, gain=1.414)
+        self.unpooling_indices = None
+        self.graclus_fn = None          # optional: callable(edge_index, weight, num_nodes) -> cluster
+        self.last_clusters = None       # raw cluster vectors of the last forward (int64)
+        self._unpool_index = None
+
+    # -- edge weight fed to the matching (no gradient is needed: it only drives integer matching)
+    def _get_edge_weight(self, data):
+        x = data.x
+        g = graph_of(data.edge_index, x.shape[0])
+        if g.E == 0:
+            return None
+        w = getattr(data, 'edge_weight', None)
+        if w is not None:
+            w = g.weights_sorted(w)
+        # the reference rewrites its input loop-free (net_util.py:166-167)
+        data.edge_index = g.coo64()
+        data.edge_weight = w
+        t = self.edge_weight_type
+        if t == -1:
+            return None
+        if t == 0:
+            return w
+        if t == 10:
+            out = torch.empty_like(w)
+            L.call('geobi_edge_weight_t10', L.ptr(x.detach().contiguous()), x.shape[1], L.ptr(g.ensure_rows()),
+                   L.ptr(g.col_out), L.ptr(w), g.E, L.ptr(out), L.stream())
+            return out
+        if t == 1:
+            return _feature_gauss(x, g, self.wei_param)
+        if t == 2:
+            return w * _feature_gauss(x, g, self.wei_param)
+        if t in (3, 4, 5):
+            xx = x.detach() if t == 3 else F.leaky_relu(self.lin(x.detach()), 0.2)
+            al, ar = (xx * self.att_l).sum(-1), (xx * self.att_r).sum(-1)
+            r, c = g.ensure_rows().long(), g.col_out.long()
+            a = torch.sigmoid((al[r] + ar[c]) + (al[c] + ar[r])).detach()
+            return a if t in (3, 4) else (a + w) / 2
+        if t == 6:
+            return _minmax(w)
+        if t == 7:
+            return _minmax(torch.log(_feature_gauss(x, g, 2).clamp_min(1e-38)) * 2)
+        if t == 8:
+            return _minmax(_feature_gauss(x, g, 2))
+        if t == 9:
+            return _minmax(w) + _minmax(_feature_gauss(x, g, 2))
+        return w
+
+    def forward(self, data, visual=False):
+        L.require_device(data.x, 'data.x')
+        edge_weight = self._get_edge_weight(data)
+        x, pos = data.x, getattr(data, 'pos', None)
+        g = graph_of(data.edge_index, x.shape[0])
+        edge_dual = getattr(data, 'edge_dual', None)
+        face = getattr(data, 'fv_indices', None)
+
+        clusts, raw = [], []
+        for _ in range(self.pool_step):
+            given = None
+            if self.graclus_fn is not None:
+                given = _i32(self.graclus_fn(g.coo64(), edge_weight, g.N))
+            cnew, g_c, w_c, cl_raw = _coarsen(g, edge_weight, given)
+            raw.append(cl_raw.long())
+            clusts.append(cnew)
+            sidx = ops.SegmentIndex(cnew, g_c.N)
+            x = _pool_features(x, sidx, self.pool_type)
+            pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+            edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
+            g, edge_weight = g_c, w_c
+            if g.E == 0:
+                break
+
+        clust = _compose(clusts)
+        self.unpooling_indices = clust.long()
+        self._unpool_index = ops.SegmentIndex(clust, g.N)
+        self.last_clusters = raw
+        out = Data(x, g.coo64(), edge_dual=edge_dual, edge_weight=edge_weight, pos=pos, fv_indices=face)
+        return out
+
+    def unpooling(self, x):
+        if self.unpooling_indices is None:
+            return x
+        return ops.UnpoolFn.apply(x, self._unpool_index)
+
+
+# ------------------------------------------------------------------------ functional API
+def pool_edge(cluster, edge_index, edge_attr=None, op='mean'):
+    """net_util.py:289-295.  cluster: consecutive ids [N]; returns ((row, col)-sorted COO, mean weights)."""
+    if op != 'mean':
+        raise NotImplementedError("pool_edge: only op='mean' is used by the reference")
+    g = graph_of(edge_index, cluster.size(0))
+    w = None if edge_attr is None else g.weights_sorted(edge_attr)
+    rowptr_c, row_c, col_c, w_c, count = _pool_edge_raw(_i32(cluster), g, w)
+    ec = int(count.item())
+    ei = torch.stack([row_c[:ec].long(), col_c[:ec].long()], 0)
+    return ei, (None if w_c is None else w_c[:ec])
+
+
+def pool_face(cluster, fv_indices):
+    face = cluster[fv_indices.view(-1)].view(-1, 3)
+    invalid = (face[:, 0] == face[:, 1]) | (face[:, 0] == face[:, 2]) | (face[:, 1] == face[:, 2])
+    return face[~invalid]
+
+
+def pooling(data, p_type='max', level=2, wei_type=0):
+    """net_util.py:305-343: on-the-fly pooling; returns (coarse Data, composed cluster index)."""
+    x, pos = data.x, getattr(data, 'pos', None)
+    g = graph_of(data.edge_index, x.shape[0])
+    if wei_type == 0:
+        w = getattr(data, 'edge_weight', None)
+        w = None if w is None else g.weights_sorted(w)
+    elif wei_type == 1:
+        nrm = (x.detach() ** 2).sum(1)
+        w = ((nrm[g.ensure_rows().long()] - nrm[g.col_out.long()]) ** 2 / (-2)).exp()
+    else:
+        w = _feature_gauss(x, g, 2)
+    clusts = []
+    for _ in range(level):
+        cnew, g_c, w_c, _ = _coarsen(g, w)
+        clusts.append(cnew)
+        sidx = ops.SegmentIndex(cnew, g_c.N)
+        x = _pool_features(x, sidx, p_type)
+        pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+        g, w = g_c, w_c
+        if g.E == 0:
+            break
+    return Data(x, g.coo64(), pos=pos, edge_weight=w), _compose(clusts).long()
+
+
+def pooling_pre(data, step=2, level=2):
+    """net_util.py:346-366: precompute the cluster hierarchy from the static edge weights."""
+    n = data.num_nodes
+    g = graph_of(data.edge_index, n)
+    w = getattr(data, 'edge_weight', None)
+    w = None if w is None else g.weights_sorted(w)
+    for i in range(1, level + 1):
+        clusters = []
+        for _ in range(step):
+            cnew, g, w, _ = _coarsen(g, w)
+            clusters.append(cnew.long())
+        setattr(data, 'pool_l%d' % i, {'clusters': clusters, 'cluster_inv': _compose(clusters).long()})
+    data.edge_weight = None
+    return data
+
+
+def pooling_run(data, pool_info, p_type='max'):
+    """net_util.py:369-380: replay precomputed clusters."""
+    x, pos = data.x, getattr(data, 'pos', None)
+    g = graph_of(data.edge_index, x.shape[0])
+    for clust in pool_info['clusters']:
+        c32 = _i32(clust)
+        nc = int(clust.max().item()) + 1
+        sidx = ops.SegmentIndex(c32, nc)
+        x = _pool_features(x, sidx, p_type)
+        pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+        rowptr_c, row_c, col_c, _, count = _pool_edge_raw(c32, g, None)
+        ec = int(count.item())
+        g = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec])
+    return Data(x, g.coo64(), pos=pos)

@@ -1,0 +1,149 @@
+"""DualGNN / GNNModule and the loss + metric functions behind the reference's ``network`` surface.
+
+Mirrors /root/reference/code/network.py:254-343 (GNNModule, DualGNN) and :347-413 (losses, errors):
+same class names, constructor arguments, child-module names and therefore state-dict keys
+(``gnn_v.l_conv1.lin.weight`` ... ``fc_f2.bias``).  The per-layer glue that the reference leaves to
+PyTorch eager ops is folded into the HIP calls: the leaky_relu after a conv and the skip
+concatenations ride inside geobi_feast_fwd, the heads + residual / normalisation inside
+geobi_head_fwd, the centroid/normal coupling inside geobi_face_geom_fwd.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .feast_conv import FeaStConv
+from .net_util import PoolingLayer
+
+LEAK = 0.2
+
+
+class GNNModule(nn.Module):
+    def __init__(self, in_channel=6, pool_type='max', pool_step=2, edge_weight_type=0, wei_param=2):
+        super().__init__()
+        self.l_conv1 = FeaStConv(in_channel, 32, 9)
+        self.pooling1 = PoolingLayer(32, pool_type, pool_step, edge_weight_type, wei_param)
+        self.l_conv2 = FeaStConv(32, 64, 9)
+        self.pooling2 = PoolingLayer(64, pool_type, pool_step, edge_weight_type, wei_param)
+        self.l_conv3 = FeaStConv(64, 128, 9)
+        self.l_conv4 = FeaStConv(128, 128, 9)
+
+        self.r_conv1 = FeaStConv(128, 64, 9)
+        self.r_conv2 = FeaStConv(128, 64, 9)
+        self.r_conv3 = FeaStConv(64, 32, 9)
+        self.r_conv4 = FeaStConv(64, 32, 9)
+
+    def forward(self, data_r1, plot_pool=False):
+        # level 0
+        data_r1.x = self.l_conv1(data_r1.x, data_r1.edge_index, slope=LEAK)
+        data_r2 = self.pooling1(data_r1)
+        # level 1
+        data_r2.x = self.l_conv2(data_r2.x, data_r2.edge_index, slope=LEAK)
+        data_r3 = self.pooling2(data_r2)
+        # level 2
+        data_r3.x = self.l_conv3(data_r3.x, data_r3.edge_index, slope=LEAK)
+        data_r3.x = self.l_conv4(data_r3.x, data_r3.edge_index, slope=LEAK)
+        # up to level 1: r_conv1 has no activation; the skip cat feeds r_conv2 as two halves
+        up2 = self.r_conv1(self.pooling2.unpooling(data_r3.x), data_r2.edge_index)
+        data_r2.x = self.r_conv2(data_r2.x, data_r2.edge_index, x2=up2, slope=LEAK)
+        # up to level 0
+        up1 = self.r_conv3(self.pooling1.unpooling(data_r2.x), data_r1.edge_index)
+        return self.r_conv4(data_r1.x, data_r1.edge_index, x2=up1, slope=LEAK)
+
+
+def _fv_index(data_f, num_vertices):
+    """int32 face->vertex table and the vertex->corner inverse lists, cached on the tensor."""
+    fv = data_f.fv_indices
+    cache = getattr(fv, '_geobi_fv', None)
+    if cache is None or cache[2] != num_vertices:
+        fv32 = fv.to(torch.int32).contiguous()
+        cidx = ops.SegmentIndex(fv32.view(-1), num_vertices)
+        cache = (fv32, cidx, num_vertices)
+        fv._geobi_fv = cache
+    return cache[0], cache[1]
+
+
+class DualGNN(nn.Module):
+    def __init__(self, force_depth=False, pool_type='max', edge_weight_type=10, wei_param=2):
+        super().__init__()
+        self.force_depth = force_depth
+
+        # graph-v
+        self.gnn_v = GNNModule(6, pool_type, 2, edge_weight_type, wei_param)
+        self.fc_v1 = nn.Linear(32, 1024)
+        self.fc_v2 = nn.Linear(1024, 1) if self.force_depth else nn.Linear(1024, 3)
+
+        # graph-f
+        self.gnn_f = GNNModule(12, pool_type, 2, edge_weight_type, wei_param)
+        self.fc_f1 = nn.Linear(32, 1024)
+        self.fc_f2 = nn.Linear(1024, 3)
+
+    def forward(self, dual_data):
+        data_v, data_f = dual_data
+        L.require_device(data_v.x, 'data_v.x')
+        x_v0 = data_v.x.contiguous()          # xyz = x[:, :3] is read in place as the head's residual
+        dd = data_v.depth_direction if self.force_depth else None
+
+        feat_v = self.gnn_v(data_v)
+        verts = ops.HeadFn.apply(feat_v, self.fc_v1.weight, self.fc_v1.bias, self.fc_v2.weight, self.fc_v2.bias,
+                                 0, dd, x_v0)
+
+        # new node feature of the facet graph: centroid + normal of the PREDICTED geometry
+        fv32, corner_index = _fv_index(data_f, verts.shape[0])
+        data_f.x = ops.FaceGeomFn.apply(verts, data_f.x, fv32, corner_index)
+
+        feat_f = self.gnn_f(data_f)
+        normals = ops.HeadFn.apply(feat_f, self.fc_f1.weight, self.fc_f1.bias, self.fc_f2.weight, self.fc_f2.bias,
+                                   1, None, None)
+        return verts, normals, None
+
+
+# ---------------------------------------------------------------------------------------
+def loss_v(vp, v, dis='L2', apply_icp=False):
+    if apply_icp:
+        raise NotImplementedError('ICP alignment needs pytorch3d, which the reference treats as optional')
+    if dis == 'L1':
+        return (vp - v).abs().sum(1).mean()
+    if dis == 'L2':
+        return (vp - v).pow(2).sum(1).mean()
+    raise NotImplementedError("loss_v: %r relies on kaolin, which the reference never imports" % (dis,))
+
+
+def loss_n(np, n, norm='L1', fc_p=None, fc=None):
+    if norm == 'L1':
+        return (np - n).abs().sum(1).mean()
+    if norm == 'L2':
+        return (np - n).pow(2).sum(1).mean()
+    raise NotImplementedError("loss_n: %r relies on kaolin, which the reference never imports" % (norm,))
+
+
+def dual_loss(loss_v, loss_n, v_scale=1, n_scale=1, alpha=None):
+    if alpha is None:
+        return loss_v * v_scale + loss_n * n_scale
+    return alpha * loss_v * v_scale + (1 - alpha) * loss_n * n_scale
+
+
+def error_v(vp, v):
+    """Mean Euclidean distance."""
+    return (vp - v).pow(2).sum(1).pow(0.5).mean()
+
+
+def error_n(np, n):
+    """Mean angle (degrees) between unit normals."""
+    error = (np - n).pow(2).sum(1)
+    val = torch.clamp(1 - error / 2, min=-1, max=1)
+    return (torch.acos(val) * 180 / math.pi).mean()
+
+
+def laplacian_loss(vp, v, edge_idx_v, normal=None):
+    keep = edge_idx_v[0] != edge_idx_v[1]
+    row, col = edge_idx_v[0][keep], edge_idx_v[1][keep]
+    n = vp.shape[0]
+    cnt = torch.bincount(row, minlength=n).clamp(min=1).to(vp.dtype).unsqueeze(1)
+
+    def lap(p):
+        out = torch.zeros_like(p).index_add_(0, row, p[row] - p[col]) / cnt
+        return out if normal is None else normal * (out * normal).sum(1, keepdim=True)
+    return (lap(vp) - lap(v)).abs().sum(1).mean()

@@ -1,0 +1,243 @@
+"""torch.autograd.Function wrappers over the C ABI (include/geobi_hip.h).
+
+Each Function replaces one third-party op of the reference's hot path; the replaced call
+site is cited in the docstring.  Tensors are allocated by PyTorch's caching allocator and
+handed to the library as borrowed device pointers on torch's current HIP stream.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+LEAK = 0.2
+HP = 12   # GEOBI_HEAD_STRIDE
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise L.GeobiError('expected float32, got %s' % t.dtype)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- FeaSt conv
+class FeastConvFn(Function):
+    """torch_geometric.nn.FeaStConv forward/backward (network.py:271-299), optionally fused with
+    the following leaky_relu (``slope``) and the skip concatenation (input given as xa | xb)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, lin_w, u_w, c, bias, graph, slope):
+        L.require_device(xa, 'x')
+        g = graph.ensure_in()
+        xa = _f32c(xa)
+        xb = None if xb is None else _f32c(xb)
+        lin_w, u_w, c, bias = _f32c(lin_w), _f32c(u_w), _f32c(c), _f32c(bias)
+        N, Ca = xa.shape
+        Cb = 0 if xb is None else xb.shape[1]
+        Cin, Cout = Ca + Cb, bias.shape[0]
+        if N != g.N:
+            raise L.GeobiError('FeaStConv: x has %d rows but the graph has %d nodes' % (N, g.N))
+        if lin_w.shape != (9 * Cout, Cin) or u_w.shape != (9, Cin) or c.shape != (9,):
+            raise L.GeobiError('FeaStConv: parameter shapes do not match heads=9, in=%d, out=%d' % (Cin, Cout))
+        dev = xa.device
+        lib = L.lib()
+        ldz = lib.geobi_feast_ldz(Cin)
+        out = torch.empty((N, Cout), dtype=torch.float32, device=dev)
+        p = torch.empty((N, HP), dtype=torch.float32, device=dev)
+        z = torch.empty((N, ldz), dtype=torch.float32, device=dev)
+        ws = L.workspace(lib.geobi_feast_fwd_ws_bytes(N, Cin, Cout), dev)
+        L.call('geobi_feast_fwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
+               L.ptr(lin_w), L.ptr(u_w), L.ptr(c), L.ptr(bias), Cout, float(slope), L.ptr(out), L.ptr(p), L.ptr(z),
+               L.ptr(ws), ws.numel(), L.stream())
+        ctx.graph, ctx.slope, ctx.has_b = g, float(slope), xb is not None
+        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xa, xb, lin_w, u_w, c, out, p, z = ctx.saved_tensors
+        g = ctx.graph
+        if not ctx.has_b:
+            xb = None
+        N, Ca = xa.shape
+        Cb = 0 if xb is None else xb.shape[1]
+        Cin, Cout = Ca + Cb, out.shape[1]
+        dev = xa.device
+        gout = _f32c(gout)
+        need_dx = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
+        dxa = torch.empty_like(xa) if need_dx else None
+        dxb = torch.empty_like(xb) if (need_dx and xb is not None) else None
+        dlin, du, dc = torch.empty_like(lin_w), torch.empty_like(u_w), torch.empty_like(c)
+        dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
+        ws = L.workspace(L.lib().geobi_feast_bwd_ws_bytes(N, g.E, Cin, Cout), dev)
+        L.call('geobi_feast_bwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
+               L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
+               ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
+               L.ptr(du), L.ptr(dc), L.ptr(dbias), L.ptr(ws), ws.numel(), L.stream())
+        return dxa, dxb, dlin, du, dc, dbias, None, None
+
+
+def feast_conv(x, graph, lin_w, u_w, c, bias, slope=1.0, x2=None):
+    return FeastConvFn.apply(x, x2, lin_w, u_w, c, bias, graph, slope)
+
+
+# ------------------------------------------------------------------ inverse lists / pooling
+class SegmentIndex(object):
+    """Inverse lists ``segment -> members`` of an int32 segment-id vector (sorted, deterministic)."""
+
+    def __init__(self, seg32, nseg):
+        L.require_device(seg32, 'segment ids')
+        self.seg = seg32.contiguous()
+        self.n = int(seg32.shape[0])
+        self.nseg = int(nseg)
+        dev = seg32.device
+        self.segptr = torch.empty(self.nseg + 1, dtype=torch.int32, device=dev)
+        self.members = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)[:self.n]
+        ws = L.workspace(L.lib().geobi_segment_csr_ws_bytes(self.n), dev)
+        L.call('geobi_segment_csr', L.ptr(self.seg), self.n, self.nseg, L.ptr(self.segptr), L.ptr(self.members),
+               L.ptr(ws), ws.numel(), L.stream())
+
+
+class SegmentMaxFn(Function):
+    """torch_scatter.scatter(x, cluster, dim=0, reduce='max') (net_util.py:134)."""
+
+    @staticmethod
+    def forward(ctx, x, sidx):
+        x = _f32c(x)
+        C = x.shape[1]
+        out = torch.empty((sidx.nseg, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((sidx.nseg, C), dtype=torch.int32, device=x.device)
+        L.call('geobi_segment_max_fwd', L.ptr(x), C, L.ptr(sidx.segptr), L.ptr(sidx.members), sidx.nseg, L.ptr(out),
+               L.ptr(arg), L.stream())
+        ctx.save_for_backward(arg)
+        ctx.n_fine = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (arg,) = ctx.saved_tensors
+        gout = _f32c(gout)
+        nseg, C = gout.shape
+        gx = torch.empty((ctx.n_fine, C), dtype=torch.float32, device=gout.device)
+        L.call('geobi_segment_max_bwd', L.ptr(gout), L.ptr(arg), C, nseg, ctx.n_fine, L.ptr(gx), L.stream())
+        return gx, None
+
+
+class SegmentMeanFn(Function):
+    """torch_scatter.scatter(..., reduce='mean') (net_util.py:132; pool_pos :136)."""
+
+    @staticmethod
+    def forward(ctx, x, sidx):
+        x = _f32c(x)
+        C = x.shape[1]
+        out = torch.empty((sidx.nseg, C), dtype=torch.float32, device=x.device)
+        L.call('geobi_segment_sum', L.ptr(x), C, L.ptr(sidx.segptr), L.ptr(sidx.members), sidx.nseg, 1, L.ptr(out),
+               L.stream())
+        ctx.sidx = sidx
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sidx = ctx.sidx
+        gout = _f32c(gout)
+        C = gout.shape[1]
+        gx = torch.empty((sidx.n, C), dtype=torch.float32, device=gout.device)
+        L.call('geobi_segment_mean_bwd', L.ptr(gout), L.ptr(sidx.seg), L.ptr(sidx.segptr), C, sidx.n, L.ptr(gx),
+               L.stream())
+        return gx, None
+
+
+class UnpoolFn(Function):
+    """PoolingLayer.unpooling: ``x[unpooling_indices]`` (net_util.py:242-245); the backward is a
+    sorted-segment sum through the inverse lists instead of an atomic index_add."""
+
+    @staticmethod
+    def forward(ctx, x, sidx):
+        x = _f32c(x)
+        C = x.shape[1]
+        out = torch.empty((sidx.n, C), dtype=torch.float32, device=x.device)
+        L.call('geobi_gather_rows', L.ptr(x), L.ptr(sidx.seg), C, sidx.n, L.ptr(out), L.stream())
+        ctx.sidx = sidx
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sidx = ctx.sidx
+        gout = _f32c(gout)
+        C = gout.shape[1]
+        gx = torch.empty((sidx.nseg, C), dtype=torch.float32, device=gout.device)
+        L.call('geobi_segment_sum', L.ptr(gout), C, L.ptr(sidx.segptr), L.ptr(sidx.members), sidx.nseg, 0,
+               L.ptr(gx), L.stream())
+        return gx, None
+
+
+# ----------------------------------------------------------------------- geometry / heads
+class FaceGeomFn(Function):
+    """network.py:335-337 + data_util.computer_face_normal: x_f = cat(x_f, centroid, unit normal)."""
+
+    @staticmethod
+    def forward(ctx, verts, xf, fv32, corner_index):
+        verts, xf = _f32c(verts), _f32c(xf)
+        F = fv32.shape[0]
+        out = torch.empty((F, 12), dtype=torch.float32, device=verts.device)
+        L.call('geobi_face_geom_fwd', L.ptr(verts), L.ptr(fv32), L.ptr(xf), xf.shape[1], F, L.ptr(out), L.stream())
+        ctx.save_for_backward(verts, fv32)
+        ctx.corner_index = corner_index
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        verts, fv32 = ctx.saved_tensors
+        cidx = ctx.corner_index
+        gout = _f32c(gout)
+        F = fv32.shape[0]
+        cg = torch.empty((3 * F, 3), dtype=torch.float32, device=gout.device)
+        L.call('geobi_face_geom_bwd', L.ptr(verts), L.ptr(fv32), L.ptr(gout), F, L.ptr(cg), L.stream())
+        gv = torch.empty((cidx.nseg, 3), dtype=torch.float32, device=gout.device)
+        L.call('geobi_segment_sum', L.ptr(cg), 3, L.ptr(cidx.segptr), L.ptr(cidx.members), cidx.nseg, 0, L.ptr(gv),
+               L.stream())
+        return gv, None, None, None
+
+
+class HeadFn(Function):
+    """fc2(leaky_relu(fc1 x)) + finish (network.py:324-332 vertex head, :340-343 face head)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, mode, dd, resid):
+        x, w1, b1, w2, b2 = _f32c(x), _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
+        N, Cin = x.shape
+        K, nout = w1.shape[0], w2.shape[0]
+        dev = x.device
+        h = torch.empty((N, K), dtype=torch.float32, device=dev)
+        raw = torch.empty((N, nout), dtype=torch.float32, device=dev)
+        out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        dd = None if dd is None else _f32c(dd)
+        ld_resid = 0
+        if resid is not None:
+            if resid.stride(1) != 1:
+                raise L.GeobiError('head: residual rows must be contiguous')
+            ld_resid = resid.stride(0)
+        L.call('geobi_head_fwd', L.ptr(x), Cin, N, L.ptr(w1), L.ptr(b1), K, L.ptr(w2), L.ptr(b2), nout, LEAK, mode,
+               L.ptr(dd), None if resid is None else resid.data_ptr(), ld_resid, L.ptr(h), L.ptr(raw), L.ptr(out),
+               L.stream())
+        ctx.mode = mode
+        ctx.has_dd = dd is not None
+        ctx.save_for_backward(x, w1, w2, h, raw, dd if dd is not None else raw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w1, w2, h, raw, dd = ctx.saved_tensors
+        if not ctx.has_dd:
+            dd = None
+        gout = _f32c(gout)
+        N, Cin = x.shape
+        K, nout = w1.shape[0], w2.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw1, db1 = torch.empty_like(w1), torch.empty(K, dtype=torch.float32, device=dev)
+        dw2, db2 = torch.empty_like(w2), torch.empty(nout, dtype=torch.float32, device=dev)
+        ws = L.workspace(L.lib().geobi_head_bwd_ws_bytes(N, Cin, K), dev)
+        L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), K, L.ptr(w2), nout, LEAK, ctx.mode, L.ptr(dd),
+               L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2),
+               L.ptr(ws), ws.numel(), L.stream())
+        return dx, dw1, db1, dw2, db2, None, None, None

@@ -1,0 +1,171 @@
+/* libgeobi_hip.so -- C ABI of the MI355X-native bi-domain mesh-graph convolution path.
+ *
+ * The reference (zhangyk18/GeoBi-GNN) has no FFI layer: its "operator API" for this path is the
+ * Python nn.Module surface (code/network.py:254-343, code/net_util.py:56-380) over third-party
+ * PyTorch extensions.  Each entry point below replaces the native kernel(s) one of those call
+ * sites dispatches to; the replaced call site is cited per function.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a BORROWED device pointer (HBM) unless marked `host`; the library never
+ *     allocates, frees or synchronises: scratch comes in through `ws` / `ws_bytes` (query the size
+ *     with the matching *_ws_bytes function, which is a pure host computation + rocPRIM size query)
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
+ *   - return value 0 = ok, non-zero = error; the message is in geobi_last_error() (thread-local)
+ *   - node features are row-major fp32; indices inside the library are int32 (max 2^31-1 edges);
+ *     the reference's int64 COO `edge_index` is accepted by geobi_csr_from_coo
+ *   - FeaSt heads are fixed at 9 (every FeaStConv on the path is built with heads=9,
+ *     code/network.py:258-268); per-node / per-edge head vectors use a padded row stride of
+ *     GEOBI_HEAD_STRIDE floats
+ */
+#ifndef GEOBI_HIP_H_
+#define GEOBI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOBI_HEADS 9
+#define GEOBI_HEAD_STRIDE 12
+
+int geobi_version(void);
+const char* geobi_last_error(void);
+
+/* ---------------------------------------------------------------- adjacency (CSR) ----------
+ * Replaces the per-call COO handling inside torch_geometric.MessagePassing / remove_self_loops /
+ * add_self_loops (FeaStConv.forward, called at code/network.py:271-299) and the CSR build inside
+ * torch_cluster.graclus (code/net_util.py:127).
+ *
+ * geobi_csr_from_coo: sort E (segment, neighbour) int64 pairs by (segment, neighbour); self loops
+ * are dropped when drop_self != 0.  rowptr[N] is the number of kept edges; col / eid have E slots
+ * (eid[k] = position of sorted edge k in the input COO).
+ * geobi_csr_transpose: CSR of the reversed edges; pos_t[e'] = index of that edge in the input CSR,
+ * inv_pos[e] = index of input edge e in the transposed CSR (either may be NULL... pos_t may not). */
+size_t geobi_csr_ws_bytes(int64_t E, int64_t N);
+int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self,
+                       int32_t* rowptr, int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, void* stream);
+int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
+                        int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream);
+int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream);
+int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream);
+
+/* ---------------------------------------------------------------- FeaSt convolution --------
+ * Replaces torch_geometric.nn.FeaStConv.forward / its autograd (16 call sites,
+ * code/network.py:271,279,286,287,290,293,296,299), optionally fused with the leaky_relu that
+ * follows most of them (slope = 1 disables it) and with the skip concatenation of
+ * code/network.py:292,298 (the input may be given as two equal halves xa | xb; Cb = 0 otherwise).
+ *
+ *   in-CSR  : rowptr_in/col_in   -- for every TARGET node its SOURCE nodes (edge_index[0] -> [1])
+ *   out-CSR : rowptr_out/col_out -- for every SOURCE node its TARGET nodes; pos_in[e] = position of
+ *             out-edge e in the in-CSR.  Both without self loops (one per node is implied).
+ *   lin_w [9*Cout, Cin], u_w [9, Cin], c [9], bias [Cout]   (PyG >= 2.0 state-dict layout)
+ *   forward saves p [N, 12] (x u^T) and z [N, geobi_feast_ldz(Cin)] (aggregated features) for the
+ *   backward; `out` after the activation is needed by the backward when slope != 1.
+ *   E = number of edges in the CSR (used for scratch sizing and byte accounting only).
+ *   Supported channel counts: Cin, Cout in {6, 12, 32, 64, 128} (Cout: 32, 64, 128).           */
+int geobi_feast_ldz(int Cin);
+size_t geobi_feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
+int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
+                    const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
+                    const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
+                    void* ws, size_t ws_bytes, void* stream);
+size_t geobi_feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
+/* dxa/dxb may be NULL (input needs no gradient); dlin_w/du_w/dc/dbias are overwritten. */
+int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
+                    const int32_t* rowptr_in, const int32_t* col_in, const int32_t* rowptr_out,
+                    const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
+                    const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
+                    const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc, float* dbias,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- pooling ------------------
+ * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10
+ *                         (code/net_util.py:226-230):  w_out = w_in + exp(-|x_row - x_col|^2 / 2)
+ * geobi_match_heavy_edge: torch_cluster.graclus (code/net_util.py:127,325,353): heavy-edge matching,
+ *                         cluster[u] = cluster[v] = min(u, v), unmatched -> own id.  Deterministic
+ *                         (greedy in descending edge order); status[0] = nodes left undecided after
+ *                         `rounds` proposal rounds (0 = converged; they are closed as singletons).
+ * geobi_relabel_compact : torch_geometric consecutive_cluster (code/net_util.py:128): dense ids by
+ *                         ascending cluster id; count[0] = number of clusters (device int32).
+ * geobi_segment_csr     : inverse lists segment -> members (ascending), the sorted-segment form of
+ *                         torch_scatter's index argument.
+ * geobi_segment_max_*   : torch_scatter.scatter(reduce='max') + backward (code/net_util.py:134);
+ *                         first maximum wins, empty segments give 0.
+ * geobi_segment_sum     : scatter(reduce='sum'|'mean') forward (code/net_util.py:132) and the
+ *                         backward of the unpool gather `x[unpooling_indices]` (:242-245).
+ * geobi_gather_rows     : PoolingLayer.unpooling forward (code/net_util.py:242-245).
+ * geobi_pool_edge       : pool_edge (code/net_util.py:289-295): relabel endpoints, drop loops,
+ *                         sort by (row, col), merge duplicates (mean of weights).  Outputs sized for
+ *                         E entries / nmax+1 row pointers; count[0] = kept edges (device int32).   */
+int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,
+                          int64_t E, float* w_out, void* stream);
+size_t geobi_match_ws_bytes(int64_t N);
+int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
+                           int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+size_t geobi_relabel_ws_bytes(int64_t N);
+int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws,
+                          size_t ws_bytes, void* stream);
+size_t geobi_segment_csr_ws_bytes(int64_t n);
+int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
+                      size_t ws_bytes, void* stream);
+int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
+                          float* out, int32_t* arg, void* stream);
+int geobi_segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
+                          void* stream);
+int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
+                      float* out, void* stream);
+int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine,
+                           float* gx, void* stream);
+int geobi_gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, void* stream);
+size_t geobi_pool_edge_ws_bytes(int64_t E);
+int geobi_pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E,
+                    int64_t nmax, int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- geometry coupling --------
+ * DualGNN.forward, code/network.py:335-337 + data_util.computer_face_normal (code/data_util.py:182-198):
+ * out[f] = (xf[f, 0:6], centroid of the predicted triangle, its unit normal).  The backward emits
+ * per-corner gradients [3F, 3] which geobi_segment_sum folds into the vertices through the
+ * vertex -> corner inverse lists.                                                               */
+int geobi_face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
+                        void* stream);
+int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout, int64_t F, float* corner_grad,
+                        void* stream);
+
+/* ---------------------------------------------------------------- heads --------------------
+ * code/network.py:324-332 (vertex head, mode 0: fc2(lrelu(fc1 x)) (* depth_direction) + xyz) and
+ * :340-343 (face head, mode 1: F.normalize(fc2(lrelu(fc1 x)), dim=1)).  h [N,K] and raw [N,nout]
+ * are saved for the backward.                                                                   */
+int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+                   const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
+                   int ld_resid, float* h, float* raw, float* out, void* stream);
+size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K);
+int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout,
+                   float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
+                   float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* ---------------------------------------------------------------- dense helpers ------------
+ * Plain fp32 MFMA GEMMs used by the layers above, exported for tests and profiling.            */
+int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
+                  int K, const float* bias, float slope, void* stream);
+size_t geobi_gemm_tn_ws_bytes(int I, int J, int64_t M);
+int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- measurement --------------
+ * When enabled, the selected kernel family is bracketed with HIP events on its launch stream
+ * (kernel: 1 = FeaSt aggregation forward, 2 = transposed aggregation backward, 3 = backward row
+ * pass).  geobi_prof_collect synchronises the recorded events and returns the launch count, the
+ * summed device time (ms) and the summed ALGORITHMIC bytes of launches whose
+ * channel count equals `tag` (tag = 0: all).                                                     */
+int geobi_prof_enable(int kernel);
+int geobi_prof_collect(int tag, int64_t* launches, double* total_ms, double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOBI_HIP_H_ */

@@ -1,0 +1,389 @@
+"""GPU parity tests, kernel by kernel: HIP path (through the C ABI) vs the CPU oracle.
+
+Bars: integer / index outputs bit-exact; floating point within 1e-5 of the fp64 oracle, relative to
+the tensor's max magnitude (the north star's "1e-5 relative fp32"), unless a test states otherwise.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _sym_graph(n, m, seed, loops=True):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (2, m), generator=g)
+    ei = torch.cat([a, a.flip(0)], 1)
+    key = torch.unique(ei[0] * n + ei[1])
+    ei = torch.stack([key // n, key % n], 0)
+    if loops:
+        ei = torch.cat([ei, torch.arange(n).repeat(2, 1)], 1)
+    return ei
+
+
+# ------------------------------------------------------------------------------- CSR
+def test_csr_from_coo_and_transpose(dev):
+    from geobi_gnn_amd.graph import Graph
+    n = 1000
+    g0 = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, n, (2, 20000), generator=g0)            # directed, duplicates, self loops
+    g = Graph.from_edge_index(ei.to(dev), n).ensure_in()
+    keep = ei[0] != ei[1]
+    r, c = ei[0][keep], ei[1][keep]
+    order = torch.argsort(r * n + c, stable=True)
+    assert g.E == int(keep.sum())
+    assert torch.equal(g.col_out.cpu().long(), c[order])
+    assert torch.equal(g.ensure_rows().cpu().long(), r[order])
+    rp = torch.zeros(n + 1, dtype=torch.long); rp[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    assert torch.equal(g.rowptr_out.cpu().long(), rp)
+    # original edge ids: the multiset of (r, c) must map back
+    eid = g.eid_out.cpu().long()
+    assert torch.equal(ei[0][eid], r[order]) and torch.equal(ei[1][eid], c[order])
+    # transposed CSR
+    order_t = torch.argsort(c[order] * n + r[order], stable=True)
+    assert torch.equal(g.col_in.cpu().long(), r[order][order_t])
+    rpt = torch.zeros(n + 1, dtype=torch.long); rpt[1:] = torch.cumsum(torch.bincount(c, minlength=n), 0)
+    assert torch.equal(g.rowptr_in.cpu().long(), rpt)
+    # pos_in: out-edge e sits at pos_in[e] of the in-CSR
+    pos_in = g.pos_in.cpu().long()
+    inv = torch.empty_like(order_t); inv[order_t] = torch.arange(order_t.numel())
+    assert torch.equal(pos_in, inv)
+
+
+def test_csr_empty_and_loops_only(dev):
+    from geobi_gnn_amd.graph import Graph
+    ei = torch.arange(5).repeat(2, 1).to(dev)
+    g = Graph.from_edge_index(ei, 5).ensure_in()
+    assert g.E == 0 and int(g.rowptr_in.abs().sum()) == 0 and int(g.rowptr_out.abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K,transB', [(300, 32, 56, 0), (1000, 64, 576, 0), (257, 128, 1152, 0),
+                                          (513, 1024, 32, 1), (129, 6, 300, 0), (77, 108, 64, 1),
+                                          (1, 32, 4, 0)])
+def test_gemm_nn(dev, M, N, K, transB):
+    from geobi_gnn_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) if transB else torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ (B.double().t() if transB else B.double()) + bias.double()
+    ref = torch.where(ref > 0, ref, ref * 0.2)
+    Ad, Bd, bd = A.to(dev), B.to(dev), bias.to(dev)
+    C = torch.empty(M, N, device=dev)
+    L.call('geobi_gemm_nn', L.ptr(Ad), K, L.ptr(Bd), B.shape[1], transB, L.ptr(C), N, M, N, K, L.ptr(bd), 0.2,
+           L.stream())
+    assert rel_err(C.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize('M,I,J', [(5000, 576, 32), (1000, 1152, 128), (4097, 9, 64), (300, 3, 1024), (7, 56, 32)])
+def test_gemm_tn(dev, M, I, J):
+    from geobi_gnn_amd import _lib as L
+    g = torch.Generator().manual_seed(M + I + J)
+    A = torch.randn(M, I + 3, generator=g)       # padded leading dimension
+    B = torch.randn(M, J, generator=g)
+    ref = A[:, :I].double().t() @ B.double()
+    Ad, Bd = A.to(dev), B.to(dev)
+    C = torch.empty(I, J, device=dev)
+    ws = L.workspace(L.lib().geobi_gemm_tn_ws_bytes(I, J, M), dev)
+    L.call('geobi_gemm_tn', L.ptr(Ad), I + 3, L.ptr(Bd), J, M, I, J, L.ptr(C), J, L.ptr(ws), ws.numel(), L.stream())
+    assert rel_err(C.cpu(), ref) < TOL
+
+
+# ------------------------------------------------------------------------- FeaSt conv
+def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0):
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    from oracle import pyg_ops as P
+    torch.manual_seed(seed)
+    ora = P.FeaStConv(Cin, Cout, 9).double()
+    hip = FeaStConv(Cin, Cout, 9).to(dev)
+    hip.load_state_dict({k: v.float() for k, v in ora.state_dict().items()})
+    x = torch.randn(n, Cin, dtype=torch.double) * xscale
+    gout = torch.randn(n, Cout, dtype=torch.double)
+    xo = x.clone().requires_grad_(True)
+    out_o = ora(xo, ei)
+    if slope != 1.0:
+        out_o = torch.nn.functional.leaky_relu(out_o, slope)
+    out_o.backward(gout)
+    eid = ei.to(dev)
+    if split:
+        xa = x[:, :Cin // 2].float().to(dev).requires_grad_(True)
+        xb = x[:, Cin // 2:].float().to(dev).requires_grad_(True)
+        out_h = hip(xa, eid, x2=xb, slope=slope)
+    else:
+        xa = x.float().to(dev).requires_grad_(True)
+        out_h = hip(xa, eid, slope=slope)
+    out_h.backward(gout.float().to(dev))
+    torch.cuda.synchronize()
+    errs = {'out': rel_err(out_h.detach().cpu(), out_o.detach())}
+    gx = torch.cat([xa.grad, xb.grad], 1) if split else xa.grad
+    errs['dx'] = rel_err(gx.cpu(), xo.grad)
+    for (k, po), (_, ph) in zip(ora.named_parameters(), hip.named_parameters()):
+        errs['d' + k] = rel_err(ph.grad.cpu(), po.grad)
+    return errs
+
+
+@pytest.mark.parametrize('Cin,Cout,slope,split', [(6, 32, 0.2, False), (12, 32, 0.2, False), (32, 64, 0.2, False),
+                                                  (64, 128, 0.2, False), (128, 128, 0.2, False),
+                                                  (128, 64, 1.0, False), (128, 64, 0.2, True),
+                                                  (64, 32, 1.0, False), (64, 32, 0.2, True)])
+def test_feast_conv_random_graph(dev, Cin, Cout, slope, split):
+    n = 700
+    ei = _sym_graph(n, 2500, seed=Cin + Cout)
+    errs = _run_feast(dev, Cin, Cout, ei, n, slope, split, seed=Cin * 7 + Cout)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_feast_conv_directed_graph_and_isolated_nodes(dev):
+    """Non-symmetric edges, duplicate edges kept, nodes without neighbours, degree > 64."""
+    n = 300
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, n - 20, (2, 4000), generator=g)          # last 20 nodes isolated
+    hub = torch.stack([torch.arange(1, 201), torch.zeros(200, dtype=torch.long)])   # node 0: in-degree 200+
+    ei = torch.cat([ei, hub], 1)
+    errs = _run_feast(dev, 32, 64, ei, n, 0.2, False, seed=11)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_feast_conv_large_logits(dev):
+    """Features of O(30) magnitude (positions scaled by 1 / mean edge length) stress the softmax."""
+    n = 500
+    ei = _sym_graph(n, 2000, seed=5)
+    errs = _run_feast(dev, 12, 32, ei, n, 0.2, False, seed=5, xscale=30.0)
+    assert max(errs.values()) < 5e-5, errs      # logits ~1e2: fp32 p_j - p_i cancellation dominates
+
+
+def test_feast_conv_deterministic(dev):
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    torch.manual_seed(0)
+    n = 2000
+    ei = _sym_graph(n, 9000, seed=9).to(dev)
+    conv = FeaStConv(64, 32, 9).to(dev)
+    x = torch.randn(n, 64, device=dev, requires_grad=True)
+    outs = []
+    for _ in range(2):
+        conv.zero_grad(); x.grad = None
+        o = conv(x, ei, slope=0.2)
+        o.square().sum().backward()
+        outs.append((o.detach().clone(), x.grad.clone(), conv.lin.weight.grad.clone(), conv.c.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)        # no atomics anywhere: bitwise reproducible
+
+
+# ---------------------------------------------------------------------- pooling kernels
+def test_edge_weight_t10(dev):
+    from geobi_gnn_amd import _lib as L
+    for C in (32, 64, 6):
+        g = torch.Generator().manual_seed(C)
+        n, E = 400, 3000
+        x = torch.randn(n, C, generator=g) * 0.5
+        row = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+        col = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+        w = torch.rand(E, generator=g)
+        ref = w.double() + ((x[row.long()].double() - x[col.long()].double()) ** 2).sum(1).div(-2).exp()
+        out = torch.empty(E, device=dev)
+        xd, rd, cd, wd = x.to(dev), row.to(dev), col.to(dev), w.to(dev)     # keep the operands alive
+        L.call('geobi_edge_weight_t10', L.ptr(xd), C, L.ptr(rd), L.ptr(cd), L.ptr(wd), E, L.ptr(out), L.stream())
+        assert rel_err(out.cpu(), ref) < TOL
+
+
+def _greedy_sorted_oracle(n, rowptr, col, w):
+    """oracle/oracle_c.c:oracle_greedy_sorted -- greedy matching in descending (w, min, max) order."""
+    from oracle import pyg_ops as P
+    lib = P._load_graclus_c()
+    assert lib, 'oracle C helper not built'
+    row = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    mn, mx = torch.minimum(row, col), torch.maximum(row, col)
+    # lexicographic: w desc, mn asc, mx asc  (stable sorts applied in reverse significance)
+    order = torch.argsort(mx, stable=True)
+    order = order[torch.argsort(mn[order], stable=True)]
+    order = order[torch.argsort(-w[order].double(), stable=True)]
+    out = torch.empty(n, dtype=torch.long)
+    args = [t.contiguous() for t in (order, row, col)]
+    lib.oracle_greedy_sorted(ctypes.c_int64(n), ctypes.c_int64(col.numel()), ctypes.c_void_p(args[0].data_ptr()),
+                             ctypes.c_void_p(args[1].data_ptr()), ctypes.c_void_p(args[2].data_ptr()),
+                             ctypes.c_void_p(out.data_ptr()))
+    return out
+
+
+@pytest.mark.parametrize('n,m,ties', [(500, 2000, False), (3000, 9000, True), (50, 40, False)])
+def test_matching_equals_sorted_greedy(dev, n, m, ties):
+    from geobi_gnn_amd.graph import Graph
+    from geobi_gnn_amd import net_util
+    ei = _sym_graph(n, m, seed=n, loops=False)
+    g = torch.Generator().manual_seed(n)
+    # symmetric weights keyed by the undirected pair
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    table = torch.rand(n * n, generator=g) if n <= 3000 else None
+    w = table[lo * n + hi]
+    if ties:
+        w = (w * 4).floor() / 4
+    gr = Graph.from_edge_index(ei.to(dev), n)
+    ws = gr.weights_sorted(w.to(dev))
+    cluster, status = net_util.hip_match(gr, ws, rounds=64)
+    assert int(status.item()) == 0
+    ref = _greedy_sorted_oracle(n, gr.rowptr_out.cpu().long(), gr.col_out.cpu().long(), ws.cpu())
+    assert torch.equal(cluster.cpu().long(), ref)
+    # validity (what graclus guarantees): clusters of <= 2 nodes, id = min member, pairs are edges
+    c = cluster.cpu().long()
+    assert int(torch.bincount(c, minlength=n).max()) <= 2
+    assert bool((c <= torch.arange(n)).all())
+    paired = torch.nonzero(c != torch.arange(n)).flatten()
+    eset = set((ei[0] * n + ei[1]).tolist())
+    assert all((int(c[u]) * n + int(u)) in eset for u in paired[:200])
+
+
+def test_relabel_matches_consecutive_cluster(dev):
+    from geobi_gnn_amd import net_util
+    from oracle import pyg_ops as P
+    g = torch.Generator().manual_seed(1)
+    n = 5000
+    cluster = torch.randint(0, n, (n,), generator=g)
+    cnew, count = net_util.relabel(cluster.to(torch.int32).to(dev))
+    ref, _ = P.consecutive_cluster(cluster)
+    assert torch.equal(cnew.cpu().long(), ref) and int(count.item()) == int(ref.max()) + 1
+
+
+@pytest.mark.parametrize('C', [3, 32, 64])
+def test_segment_max_mean_unpool(dev, C):
+    from geobi_gnn_amd import ops
+    from oracle import pyg_ops as P
+    g = torch.Generator().manual_seed(C)
+    n, nseg = 3000, 1100
+    seg = torch.randint(0, nseg - 50, (n,), generator=g)          # the last 50 segments stay empty
+    x = torch.randn(n, C, generator=g)
+    x[::7] = x[1::7][:x[::7].shape[0]]                             # exact ties between rows
+    gout = torch.randn(nseg, C, generator=g)
+    sidx = ops.SegmentIndex(seg.to(torch.int32).to(dev), nseg)
+    for red, fn in (('max', ops.SegmentMaxFn), ('mean', ops.SegmentMeanFn)):
+        xo = x.clone().requires_grad_(True)
+        ref = P.scatter(xo, seg, dim=0, dim_size=nseg, reduce=red)
+        ref.backward(gout)
+        xh = x.to(dev).requires_grad_(True)
+        out = fn.apply(xh, sidx)
+        out.backward(gout.to(dev))
+        if red == 'max':
+            assert torch.equal(out.detach().cpu(), ref.detach())          # selection: bit-exact
+            assert torch.equal(xh.grad.cpu(), xo.grad)
+        else:
+            assert rel_err(out.detach().cpu(), ref.detach()) < TOL
+            assert rel_err(xh.grad.cpu(), xo.grad) < TOL
+    # unpool gather + sorted-segment-sum backward
+    xc = torch.randn(nseg, C, generator=g)
+    gf = torch.randn(n, C, generator=g)
+    xo = xc.clone().requires_grad_(True)
+    xo[seg].backward(gf)
+    xh = xc.to(dev).requires_grad_(True)
+    out = ops.UnpoolFn.apply(xh, sidx)
+    out.backward(gf.to(dev))
+    assert torch.equal(out.detach().cpu(), xc[seg])
+    assert rel_err(xh.grad.cpu(), xo.grad.double()) < TOL
+
+
+def test_pool_edge_matches_oracle(dev):
+    from geobi_gnn_amd import net_util
+    from oracle import ref_model as R
+    n = 2000
+    ei = _sym_graph(n, 8000, seed=4)
+    g = torch.Generator().manual_seed(4)
+    w = torch.rand(ei.shape[1], generator=g)
+    cluster = torch.randint(0, 700, (n,), generator=g)
+    cluster = torch.unique(cluster, return_inverse=True)[1]          # consecutive ids
+    ref_i, ref_w = R.pool_edge(cluster, ei, w)
+    out_i, out_w = net_util.pool_edge(cluster.to(dev), ei.to(dev), w.to(dev))
+    assert torch.equal(out_i.cpu(), ref_i)
+    assert rel_err(out_w.cpu(), ref_w.double()) < 1e-6
+    out_i2, none_w = net_util.pool_edge(cluster.to(dev), ei.to(dev))
+    assert torch.equal(out_i2.cpu(), ref_i) and none_w is None
+    # reference fixture (pool_edge / pool_face run through the reference's own net_util.py)
+    from helpers import load_fixture
+    fx = load_fixture('pure_functions.npz')
+    t = lambda k: torch.from_numpy(fx[k])
+    oi, ow = net_util.pool_edge(t('cluster').long().to(dev), t('edge_index').long().to(dev), t('calc_weight').to(dev))
+    assert torch.equal(oi.cpu(), t('pool_edge_index').long())
+    assert rel_err(ow.cpu(), t('pool_edge_weight').double()) < 1e-6
+    assert torch.equal(net_util.pool_face(t('cluster').long().to(dev), t('faces').long().to(dev)).cpu(),
+                       t('pool_face').long())
+
+
+# ----------------------------------------------------------------- geometry and heads
+def test_face_geom(dev):
+    from geobi_gnn_amd import ops, meshgen
+    from oracle import ref_model as R
+    noisy, _, faces = meshgen.noisy_icosphere(6, 0.3, seed=2)
+    verts = torch.from_numpy(noisy).double() * 7.0
+    fv = torch.from_numpy(faces)
+    xf = torch.randn(fv.shape[0], 6, dtype=torch.double)
+    gout = torch.randn(fv.shape[0], 12, dtype=torch.double)
+    vo = verts.clone().requires_grad_(True)
+    ref = torch.cat((xf, vo[fv].mean(1), R.computer_face_normal(vo, fv)), 1)
+    ref.backward(gout)
+    fv32 = fv.to(torch.int32).to(dev)
+    cidx = ops.SegmentIndex(fv32.view(-1), verts.shape[0])
+    vh = verts.float().to(dev).requires_grad_(True)
+    out = ops.FaceGeomFn.apply(vh, xf.float().to(dev), fv32, cidx)
+    out.backward(gout.float().to(dev))
+    assert rel_err(out.detach().cpu(), ref.detach()) < TOL
+    assert rel_err(vh.grad.cpu(), vo.grad) < TOL
+    # reference fixture for computer_face_normal
+    from helpers import load_fixture
+    fx = load_fixture('pure_functions.npz')
+    pts, f32 = torch.from_numpy(fx['points']).to(dev), torch.from_numpy(fx['faces']).to(dev)
+    c2 = ops.SegmentIndex(f32.view(-1), pts.shape[0])
+    o2 = ops.FaceGeomFn.apply(pts, torch.zeros(f32.shape[0], 6, device=dev), f32, c2)
+    assert rel_err(o2[:, 9:12].cpu(), torch.from_numpy(fx['face_normal']).double()) < TOL
+
+
+@pytest.mark.parametrize('mode,nout', [(0, 3), (0, 1), (1, 3)])
+def test_head(dev, mode, nout):
+    from geobi_gnn_amd import ops
+    torch.manual_seed(mode * 10 + nout)
+    n = 777
+    fc1, fc2 = torch.nn.Linear(32, 1024).double(), torch.nn.Linear(1024, nout).double()
+    x = torch.randn(n, 32, dtype=torch.double)
+    x6 = torch.randn(n, 6, dtype=torch.double)
+    dd = torch.nn.functional.normalize(torch.randn(n, 3, dtype=torch.double), dim=1)
+    gout = torch.randn(n, 3, dtype=torch.double)
+    xo = x.clone().requires_grad_(True)
+    y = fc2(torch.nn.functional.leaky_relu(fc1(xo), 0.2))
+    if mode == 0:
+        if nout == 1:
+            y = y * dd
+        ref = y + x6[:, :3]
+    else:
+        ref = torch.nn.functional.normalize(y, dim=1)
+    ref.backward(gout)
+    f = lambda t: t.detach().float().to(dev)
+    xh = f(x).requires_grad_(True)
+    ps = [f(p).requires_grad_(True) for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    out = ops.HeadFn.apply(xh, ps[0], ps[1], ps[2], ps[3], mode, f(dd) if (mode == 0 and nout == 1) else None,
+                           f(x6) if mode == 0 else None)
+    out.backward(f(gout))
+    assert rel_err(out.detach().cpu(), ref.detach()) < TOL
+    assert rel_err(xh.grad.cpu(), xo.grad) < TOL
+    for ph, po in zip(ps, (fc1.weight, fc1.bias, fc2.weight, fc2.bias)):
+        assert rel_err(ph.grad.cpu(), po.grad) < TOL
+
+
+def test_errors_are_loud(dev):
+    from geobi_gnn_amd import _lib as L
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    with pytest.raises(L.GeobiError):
+        FeaStConv(6, 32, 9)(torch.randn(10, 6), torch.zeros(2, 4, dtype=torch.long))      # CPU tensors
+    conv = FeaStConv(6, 32, 9).to(dev)
+    with pytest.raises(L.GeobiError):
+        conv(torch.randn(10, 7, device=dev), torch.zeros(2, 4, dtype=torch.long, device=dev))   # wrong width
+    with pytest.raises(L.GeobiError):
+        L.call('geobi_gemm_nn', None, 1, None, 1, 0, None, 1, 1, 1, 1, None, 1.0, L.stream())
