@@ -1,0 +1,206 @@
+"""Benchmark of the hot path: DualGNN forward + loss + backward (+ optimiser step) on synthetic meshes.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N > 1: launched through
+torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[2] "Synthetic train, batch=4 meshes (~20k faces each), fwd+bwd":
+per rank and step, 4 noisy icospheres of frequency 32 (F = 20 480, V = 10 242; 337 862 level-0
+edges each, self loops included, as the dataset delivers them) processed as one disjoint-union
+graph with per-mesh mean losses (= the reference's gradient accumulation over batch_size = 4
+single-mesh steps, train_dual.py:211-218), L1/L1 losses, Adam lr 1e-3.  Weak scaling: every rank
+owns a different batch; the only collective is the all-reduce of the 3.76 MB gradient bucket.
+Timed region: forward, loss, backward, gradient all-reduce, optimiser step.  Inputs are resident
+in HBM before the clock starts.
+
+metric  M-edges/s = level-0 edge_index columns of all meshes of all ranks / wall seconds.
+roofline  the forward FeaSt aggregation kernel ("scatter-add" of the path), its dominant
+          instantiation: ALGORITHMIC bytes (B_agg with z written out) / launch
+          time measured with HIP events on the launch stream in a separate pass.
+cpu_baseline  the PyG-shaped CPU oracle (same op decomposition as the reference) on ONE mesh of
+          the same size, all host cores, rank 0 at N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+FREQ = 32                  # icosphere frequency: F = 20 480 faces
+BATCH = 4
+
+
+def make_batch(rank, device, freq=FREQ, batch=BATCH):
+    from geobi_gnn_amd import meshgen
+    from geobi_gnn_amd.data import union_batch
+    pairs = []
+    for i in range(batch):
+        sigma = (0.1, 0.2, 0.3)[i % 3]                                   # the _n1/_n2/_n3 noise levels
+        pairs.append(meshgen.synthetic_dual_data(freq, sigma, seed=200 + rank * batch + i))
+    edges = sum(p[0].edge_index.shape[1] + p[1].edge_index.shape[1] for p in pairs)
+    dv, df = union_batch(pairs)
+    return dv.to(device), df.to(device), edges
+
+
+def train_step(net, bucket, opt, dv0, df0, collective=True):
+    from geobi_gnn_amd import network
+    from geobi_gnn_amd.parallel import batched_losses
+    bucket.zero()
+    dv, df = dv0.shallow_copy(), df0.shallow_copy()      # the forward rewrites .x on the bag it gets
+    vp, npred, _ = net((dv, df))
+    lv, ln = batched_losses(vp, npred, dv0, df0, 'L1', 'L1')
+    loss = network.dual_loss(lv, ln)
+    loss.backward()
+    if collective:
+        bucket.all_reduce_mean()
+    opt.step()
+    return loss
+
+
+def measure_roofline(net, bucket, opt, dv, df, steps=3):
+    """Separate pass: every forward-aggregation launch bracketed by HIP events on its stream."""
+    from geobi_gnn_amd import _lib as L
+    lib = L.lib()
+    lib.geobi_prof_enable(1)
+    for _ in range(steps):
+        train_step(net, bucket, opt, dv, df, collective=False)      # rank-local pass: no collective
+    torch.cuda.synchronize()
+    best = None
+    total = {'launches': 0, 'ms': 0.0, 'bytes': 0.0}
+    for tag in (6, 12, 32, 64, 128):
+        n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), 'prof_collect')
+        if n.value == 0:
+            continue
+        total['launches'] += n.value; total['ms'] += ms.value; total['bytes'] += by.value
+        if best is None or ms.value > best['ms']:
+            best = {'tag': tag, 'launches': n.value, 'ms': ms.value, 'bytes': by.value}
+    lib.geobi_prof_enable(0)
+    ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
+    return {
+        'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+        'kernel': 'feast_aggregate_kernel<%d,%d,0>' % (best['tag'], 3 if best['tag'] in (6, 12) else 4),
+        'launches': best['launches'], 'avg_us': round(best['ms'] * 1e3 / best['launches'], 2),
+        'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
+        'all_instantiations': {'launches': total['launches'],
+                               'achieved': round(total['bytes'] / (total['ms'] * 1e-3) / 1e9, 1),
+                               'avg_us': round(total['ms'] * 1e3 / total['launches'], 2)},
+    }
+
+
+def cpu_baseline(freq=FREQ, timed=3):
+    """PyG-shaped oracle, fp32, all host cores, ONE mesh of the bench size (bounded sample)."""
+    from geobi_gnn_amd import meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    dv, df = meshgen.synthetic_dual_data(freq, 0.2, seed=200)
+    edges = dv.edge_index.shape[1] + df.edge_index.shape[1]
+    torch.manual_seed(0)
+    net = R.DualGNN()
+    times = []
+    for it in range(1 + timed):
+        a = P.Data(dv.x.clone(), dv.edge_index, edge_weight=dv.edge_weight, y=dv.y)
+        b = P.Data(df.x.clone(), df.edge_index, edge_weight=df.edge_weight, y=df.y, fv_indices=df.fv_indices)
+        net.zero_grad()
+        t0 = time.perf_counter()
+        vp, npred, _ = net((a, b))
+        loss = R.dual_loss(R.loss_v(vp, a.y, 'L1'), R.loss_n(npred, b.y, 'L1'))
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {'value': round(edges / med / 1e6, 4), 'unit': 'M-edges/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 icosphere n=%d (F=%d, %d edges), fwd+loss+bwd, median of %d after 1 warm-up, %.2f s each; '
+                      'torch %s CPU, PyG-shaped per-edge op decomposition (oracle/)' %
+                      (freq, 20 * freq * freq, edges, timed, med, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--freq', type=int, default=FREQ, help=argparse.SUPPRESS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from geobi_gnn_amd import network, _lib
+    from geobi_gnn_amd.parallel import init_distributed, GradBucket
+
+    rank, world, device = init_distributed()
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no CPU fallback exists'
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    _lib.lib()
+
+    torch.manual_seed(0)                                  # random-init weights of the real architecture
+    net = network.DualGNN().to(device)
+    bucket = GradBucket(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    dv, df, edges = make_batch(rank, device, args.freq)
+
+    for _ in range(args.warmup):
+        train_step(net, bucket, opt, dv, df)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(net, bucket, opt, dv, df)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    e = torch.tensor([float(edges)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    elapsed, total_edges = float(t.item()), float(e.item())
+
+    out = {
+        'metric': 'M-edges/s (fwd+bwd) on Synthetic set',
+        'value': round(total_edges * args.steps / elapsed / 1e6, 2), 'unit': 'M-edges/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'Synthetic train, batch=4 meshes (~20k faces each), fwd+bwd '
+                               '[BASELINE.json configs[2]]: per rank 4 noisy icospheres n=%d (F=%d) as one '
+                               'disjoint-union graph, L1/L1 loss, grad all-reduce + Adam step inside the timed '
+                               'region' % (args.freq, 20 * args.freq ** 2),
+                   'meshes_per_rank': BATCH, 'edges_per_rank_step': edges, 'parallelism': 'dp%d' % world,
+                   'final_loss': round(float(loss.item()), 6)},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            out['roofline'] = measure_roofline(net, bucket, opt, dv, df)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.freq)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,11 +41,17 @@ class Data(object):
     def to(self, device, non_blocking=False):
         out = Data()
         for k, v in self.__dict__.items():
-            if k.startswith('_'):
-                continue
             if torch.is_tensor(v):
                 v = v.to(device, non_blocking=non_blocking)
             setattr(out, k, v)
+        return out
+
+    def shallow_copy(self):
+        """New attribute bag over the SAME tensors (the forward pass rewrites .x / .edge_index on
+        the bag it is given, like the reference does; cached graph structure stays attached to
+        the shared edge_index tensor)."""
+        out = Data()
+        out.__dict__.update(self.__dict__)
         return out
 
     def clone(self):

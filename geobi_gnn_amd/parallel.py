@@ -1,0 +1,102 @@
+"""Data parallelism for the mesh path: one process per GPU, meshes sharded, gradients all-reduced.
+
+The reference is single-device; its "batch_size" is gradient accumulation over sequential
+single-mesh steps (/root/reference/code/train_dual.py:211-218).  Meshes are independent units
+(no graph is ever split), so the only collective is ONE all-reduce of the flat fp32 gradient
+bucket (939 128 elements = 3.76 MB) per optimiser step -- RCCL over xGMI with backend "nccl",
+gloo on CPU for tests.  Eval metrics reduce as (sum, count) pairs like train_dual.py:246-259.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); returns (rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device('cuda', local) if use_cuda else torch.device('cpu')
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        kw = {}
+        if use_cuda:
+            kw['device_id'] = device
+        dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def shard_indices(num_items, rank, world, seed=0, epoch=0, shuffle=True):
+    """Round-robin shard of a common permutation (same seed on every rank); every item appears
+    on exactly one rank, ranks differ in length by at most one."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed * 1000003 + epoch)
+        order = torch.randperm(num_items, generator=g).tolist()
+    else:
+        order = list(range(num_items))
+    return order[rank::world]
+
+
+class GradBucket(object):
+    """All parameter gradients as views of one flat fp32 buffer: zeroing is one memset, the
+    data-parallel reduction is one all-reduce, and nothing is copied in or out."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+        for p in self.params:        # an optimizer's zero_grad(set_to_none=True) would detach the views
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr():
+                raise RuntimeError('GradBucket: a gradient view was replaced; use bucket.zero(), not zero_grad()')
+
+    def all_reduce_mean(self):
+        """Sum over ranks then divide by the world size (= the reference's loss / batch_size)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+        return self.flat
+
+
+def reduce_sums(values, device):
+    """All-reduce a list of python/tensor scalars (sums and counts of the eval loop)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if t.is_cuda:
+            t = t.float()          # RCCL path: fp32 is plenty for six scalars
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.double().tolist()
+
+
+def batched_losses(vp, npred, data_v, data_f, loss_v='L1', loss_n='L1'):
+    """Per-mesh mean losses averaged over the meshes of a disjoint-union batch.
+
+    Identical to accumulating ``loss / batch_size`` over sequential single-mesh steps
+    (train_dual.py:204-212).  Without ``mesh_ptr`` it is the plain per-node mean."""
+    def per_node(a, b, kind):
+        d = a - b
+        return d.abs().sum(1) if kind == 'L1' else d.pow(2).sum(1)
+
+    def reduce(vals, ptr):
+        if ptr is None or ptr.numel() <= 2:
+            return vals.mean()
+        counts = (ptr[1:] - ptr[:-1]).to(vals.device)
+        w = torch.repeat_interleave(1.0 / (counts.to(vals.dtype) * counts.numel()), counts)
+        return (vals * w).sum()
+
+    lv = reduce(per_node(vp, data_v.y, loss_v), getattr(data_v, 'mesh_ptr', None))
+    ln = reduce(per_node(npred, data_f.y, loss_n), getattr(data_f, 'mesh_ptr', None))
+    return lv, ln

@@ -1,0 +1,171 @@
+"""CPU tests of the host side: C-ABI surface, input contract of the generator, data-parallel
+plumbing over gloo (world_size 2).  No compute call reaches the HIP library here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from geobi_gnn_amd import _lib
+    protos = _lib.parse_header()
+    # every prototype in the public header, found independently of the binding's parser
+    src = open(_lib.HEADER).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    names = set(re.findall(r'\b(geobi_\w+)\s*\(', src))
+    assert names == set(protos), names ^ set(protos)
+    assert len(names) >= 30
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(['bash', os.path.join(ROOT, 'geobi_gnn_amd', 'csrc', 'build.sh')])
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), n
+    lib = _lib.lib()
+    assert lib.geobi_version() >= 100
+    # pure host queries work without a GPU
+    assert lib.geobi_feast_ldz(6) == 56 and lib.geobi_feast_ldz(64) == 576
+    assert lib.geobi_feast_bwd_ws_bytes(1000, 7000, 64, 32) > 0
+
+
+def test_product_refuses_cpu_tensors_and_never_imports_oracle():
+    from geobi_gnn_amd import network, meshgen, _lib
+    net = network.DualGNN()
+    dv, df = meshgen.synthetic_dual_data(2, 0.2, 0)
+    with pytest.raises(_lib.GeobiError):
+        net((dv, df))
+    for root, _, files in os.walk(os.path.join(ROOT, 'geobi_gnn_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+    text = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'cpu_baseline' in text
+
+
+def test_state_dict_keys_match_reference_layout():
+    from geobi_gnn_amd import network
+    net = network.DualGNN()
+    keys = list(net.state_dict().keys())
+    assert keys[0] == 'gnn_v.l_conv1.c' or 'gnn_v.l_conv1.lin.weight' in keys
+    assert {'gnn_v.l_conv1.lin.weight', 'gnn_v.l_conv1.u.weight', 'gnn_v.l_conv1.c', 'gnn_v.l_conv1.bias',
+            'gnn_f.r_conv4.lin.weight', 'fc_v1.weight', 'fc_v2.bias', 'fc_f1.weight', 'fc_f2.bias'} <= set(keys)
+    assert sum(p.numel() for p in net.parameters()) == 939128
+    assert sum(p.numel() for p in network.DualGNN(force_depth=True).parameters()) == 937078
+    assert net.gnn_v.l_conv1.lin.weight.shape == (9 * 32, 6) and net.gnn_f.l_conv1.u.weight.shape == (9, 12)
+    # same keys as the oracle restatement (which loads the reference's own state_dict)
+    from oracle import ref_model as R
+    assert keys == list(R.DualGNN().state_dict().keys())
+
+
+@pytest.mark.parametrize('n', [1, 3, 11])
+def test_synthetic_mesh_contract(n):
+    from geobi_gnn_amd import meshgen
+    dv, df = meshgen.synthetic_dual_data(n, 0.2, seed=n)
+    F, V = 20 * n * n, 10 * n * n + 2
+    assert dv.x.shape == (V, 6) and df.x.shape == (F, 6) and df.fv_indices.shape == (F, 3)
+    assert dv.edge_index.shape[1] == 3 * F + V
+    if n >= 3:
+        assert df.edge_index.shape[1] == 13 * F - 60
+    # vertex graph: sorted symmetric pairs, then V self loops appended (dataset.py:211-213)
+    ei = dv.edge_index
+    assert torch.equal(ei[:, -V:], torch.arange(V).repeat(2, 1))
+    body = ei[:, :-V]
+    key = body[0] * V + body[1]
+    assert bool((key[1:] > key[:-1]).all())
+    assert set(key.tolist()) == set((body[1] * V + body[0]).tolist())
+    # facet graph: row-major sorted, self loops inline (data_util.py:436-456)
+    kf = df.edge_index[0] * F + df.edge_index[1]
+    assert bool((kf[1:] > kf[:-1]).all()) and int((df.edge_index[0] == df.edge_index[1]).sum()) == F
+    assert bool((dv.edge_weight > 0).all()) and bool(torch.isfinite(df.edge_weight).all())
+    # unit normals, unit-mean-edge-length scaling
+    assert torch.allclose(dv.x[:, 3:].norm(dim=1), torch.ones(V), atol=1e-5)
+    assert torch.allclose(df.y.norm(dim=1), torch.ones(F), atol=1e-5)
+
+
+def test_union_batch_and_batched_losses():
+    from geobi_gnn_amd import meshgen
+    from geobi_gnn_amd.data import union_batch
+    from geobi_gnn_amd.parallel import batched_losses
+    a = meshgen.synthetic_dual_data(2, 0.2, 0)
+    b = meshgen.synthetic_dual_data(3, 0.3, 1)
+    dv, df = union_batch([a, b])
+    Va, Fa = a[0].x.shape[0], a[1].x.shape[0]
+    assert dv.x.shape[0] == Va + b[0].x.shape[0] and dv.mesh_ptr.tolist() == [0, Va, dv.x.shape[0]]
+    assert int(dv.edge_index[:, :a[0].edge_index.shape[1]].max()) < Va
+    assert int(dv.edge_index[:, a[0].edge_index.shape[1]:].min()) >= Va
+    assert int(df.fv_indices[Fa:].min()) >= Va
+    g = torch.Generator().manual_seed(0)
+    vp = torch.randn(dv.x.shape[0], 3, generator=g)
+    npred = torch.randn(df.x.shape[0], 3, generator=g)
+    lv, ln = batched_losses(vp, npred, dv, df)
+    want_v = 0.5 * ((vp[:Va] - a[0].y).abs().sum(1).mean() + (vp[Va:] - b[0].y).abs().sum(1).mean())
+    want_n = 0.5 * ((npred[:Fa] - a[1].y).abs().sum(1).mean() + (npred[Fa:] - b[1].y).abs().sum(1).mean())
+    assert torch.allclose(lv, want_v, rtol=1e-5) and torch.allclose(ln, want_n, rtol=1e-5)
+    sc = dv.shallow_copy()
+    sc.x = None
+    assert dv.x is not None and sc.edge_index is dv.edge_index
+
+
+def test_shard_indices_partition():
+    from geobi_gnn_amd.parallel import shard_indices
+    for world in (1, 2, 3, 8):
+        parts = [shard_indices(29, r, world, seed=5, epoch=2) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(29))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard_indices(10, 0, 2, seed=1, epoch=0) != shard_indices(10, 0, 2, seed=1, epoch=1)
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from geobi_gnn_amd import network
+from geobi_gnn_amd.parallel import init_distributed, GradBucket, reduce_sums, shard_indices
+rank, world, device = init_distributed('gloo')
+assert world == 2 and device.type == 'cpu'
+torch.manual_seed(0)
+net = network.DualGNN()                       # parameters only; no HIP call is made on CPU
+bucket = GradBucket(net.parameters())
+assert bucket.flat.numel() == 939128
+bucket.zero()
+for i, p in enumerate(net.parameters()):
+    p.grad.add_(float(rank + 1) * (i + 1))    # what backward would accumulate in place
+flat = bucket.all_reduce_mean()
+for i, p in enumerate(net.parameters()):
+    assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5 * (i + 1))), i
+# the optimiser sees the reduced gradients through the same views
+opt = torch.optim.SGD(net.parameters(), lr=1.0)
+before = net.fc_f2.bias.detach().clone()
+opt.step()
+idx = [i for i, (k, _) in enumerate(net.named_parameters()) if k == 'fc_f2.bias'][0]
+assert torch.allclose(net.fc_f2.bias, before - 1.5 * (idx + 1))
+sums = reduce_sums([rank + 1.0, 10.0], device)
+assert sums == [3.0, 20.0]
+mine = shard_indices(7, rank, world, seed=3)
+gathered = [None, None]
+dist.all_gather_object(gathered, mine)
+assert sorted(gathered[0] + gathered[1]) == list(range(7))
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', OMP_NUM_THREADS='2',
+               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29731', str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count('ok') == 2
