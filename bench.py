@@ -96,15 +96,38 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
     }
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a 1-GPU box
+    exposes every host CPU in the mask but grants a 16-core share; oversubscribing OpenMP stalls)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            pr = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16)
+
+
+def log(msg):
+    print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(freq=FREQ, timed=3):
     """PyG-shaped oracle, fp32, all host cores, ONE mesh of the bench size (bounded sample)."""
     from geobi_gnn_amd import meshgen
     from oracle import ref_model as R, pyg_ops as P
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     dv, df = meshgen.synthetic_dual_data(freq, 0.2, seed=200)
     edges = dv.edge_index.shape[1] + df.edge_index.shape[1]
@@ -120,6 +143,7 @@ def cpu_baseline(freq=FREQ, timed=3):
         loss = R.dual_loss(R.loss_v(vp, a.y, 'L1'), R.loss_n(npred, b.y, 'L1'))
         loss.backward()
         dt = time.perf_counter() - t0
+        log('cpu oracle pass %d: %.2f s on %d threads' % (it, dt, cores))
         if it > 0:
             times.append(dt)
     med = sorted(times)[len(times) // 2]
@@ -154,6 +178,7 @@ def main():
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     dv, df, edges = make_batch(rank, device, args.freq)
 
+    log('rank %d: batch resident (%d edges), warming up' % (rank, edges))
     for _ in range(args.warmup):
         train_step(net, bucket, opt, dv, df)
 
@@ -175,6 +200,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
     elapsed, total_edges = float(t.item()), float(e.item())
+    if rank == 0:
+        log('timed %d steps: %.3f ms/step' % (args.steps, elapsed / args.steps * 1e3))
 
     out = {
         'metric': 'M-edges/s (fwd+bwd) on Synthetic set',

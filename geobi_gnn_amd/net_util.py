@@ -22,6 +22,7 @@ from .data import Data
 from .graph import Graph, graph_of, attach
 
 MATCH_ROUNDS = 24
+MATCH_ROUNDS_MAX = 1536
 
 
 def _i32(t):
@@ -79,7 +80,9 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
         cnew, ncount = relabel(cluster32)
         rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
         undecided, nc, ec = torch.cat([status, ncount, ecount]).tolist()
-        if undecided:   # rare: proposal chains longer than `rounds`; redo with the bound lifted
+        if undecided and rounds < MATCH_ROUNDS_MAX:
+            # rare: proposal chains longer than `rounds`; redo with the bound lifted.  Beyond
+            # MATCH_ROUNDS_MAX the undecided nodes stay singletons (still a valid clustering).
             return _coarsen(graph, weight_sorted, None, rounds * 4)
     else:
         cnew, ncount = relabel(cluster32)
