@@ -165,7 +165,7 @@ def main():
 
     import torch.distributed as dist
     from geobi_gnn_amd import network, _lib
-    from geobi_gnn_amd.parallel import init_distributed, GradBucket
+    from geobi_gnn_amd.parallel import init_distributed, FlatParameters
 
     rank, world, device = init_distributed()
     assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no CPU fallback exists'
@@ -174,8 +174,9 @@ def main():
 
     torch.manual_seed(0)                                  # random-init weights of the real architecture
     net = network.DualGNN().to(device)
-    bucket = GradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    flat = FlatParameters(net)            # one flat parameter + one flat gradient bucket
+    bucket = flat.bucket
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-3)
     dv, df, edges = make_batch(rank, device, args.freq)
 
     log('rank %d: batch resident (%d edges), warming up' % (rank, edges))

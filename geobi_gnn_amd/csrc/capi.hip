@@ -146,9 +146,9 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
 
 size_t geobi_match_ws_bytes(int64_t N) { return match_ws_bytes(N); }
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
-                           int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+                           int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(rowptr); NOTNULL(cluster); NOTNULL(status);
-  return match_heavy_edge(rowptr, col, w, N, rounds, cluster, status, ws, ws_bytes, S(stream));
+  return match_heavy_edge(rowptr, col, w, N, rounds, init, cluster, cluster_final, status, ws, ws_bytes, S(stream));
 }
 
 size_t geobi_relabel_ws_bytes(int64_t N) { return relabel_ws_bytes(N); }
@@ -230,7 +230,10 @@ size_t geobi_gemm_tn_ws_bytes(int I, int J, int64_t M) { return gemm_tn_ws_bytes
 int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc,
                   void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(A); NOTNULL(B); NOTNULL(C);
-  return gemm_tn(A, lda, B, ldb, M, I, J, C, ldc, TN_PLAIN, 0, 0, ws, ws_bytes, S(stream));
+  TnOutput o;
+  o.C = C;
+  o.ldc = ldc;
+  return gemm_tn(A, lda, B, ldb, M, I, J, -1, -1, o, ws, ws_bytes, S(stream));
 }
 
 int geobi_prof_enable(int kernel) {

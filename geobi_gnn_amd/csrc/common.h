@@ -70,9 +70,18 @@ struct GemmEpilogue {
 int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
             const GemmEpilogue& ep, hipStream_t s);
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M);
-enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1 };
-int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc, int mode,
-            int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s);
+enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1, TN_DU_DC = 2 };
+struct TnOutput {
+  int mode = TN_PLAIN;
+  float* C = nullptr;   // primary output
+  int ldc = 0;
+  float* C2 = nullptr;  // secondary output (bias gradient / c gradient)
+  int Cin = 0, Cout = 0;
+  int extra_row = 0, extra_col = 0;  // TN_PLAIN: last row / column is the implicit-ones one -> C2
+};
+// I, J: logical output sizes INCLUDING an implicit ones row / column when ones_row / ones_col >= 0
+int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
+            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s);
 size_t colsum_ws_bytes(int64_t M, int J);
 int colsum(const float* A, int lda, int64_t M, int J, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 
@@ -94,8 +103,8 @@ int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* co
 int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s);
 int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s);
 size_t match_ws_bytes(int64_t N);
-int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
-                     int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
+int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                     int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
 size_t relabel_ws_bytes(int64_t N);
 int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws, size_t ws_bytes,
                     hipStream_t s);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void feast_rowpass_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ dz, int ldz, int N, float* __restrict__ dl, float* __restrict__ dpn,
-    float* __restrict__ dcs) {
+    float* __restrict__ dcs, int ld_dcs) {
   constexpr int G = C / VEC;
   constexpr int NPW = 64 / G;
   __shared__ __attribute__((aligned(16))) float s_slot[4][64][HP];
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void feast_rowpass_kernel(
     a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
     a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
     a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
-    float4* b = reinterpret_cast<float4*>(dcs + (size_t)node * HP);
+    float4* b = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
     b[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
     b[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
     b[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
@@ -440,12 +440,12 @@ int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const floa
 
 int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
                    const int* rowptr, const int* col, const float* dz, int ldz, int N, float* dl, float* dpn,
-                   float* dcs, hipStream_t s) {
+                   float* dcs, int ld_dcs, hipStream_t s) {
 #define GEOBI_ROW(C_, V_)                                                                                     \
   do {                                                                                                        \
     constexpr int NPW_ = 64 / (C_ / V_);                                                                      \
     feast_rowpass_kernel<C_, V_><<<cdiv(N, 4 * NPW_), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
-                                                                   N, dl, dpn, dcs);                          \
+                                                                   N, dl, dpn, dcs, ld_dcs);                  \
   } while (0)
   switch (C) {
     case 6: GEOBI_ROW(6, 3); break;
@@ -477,7 +477,7 @@ int launch_logits(int C, const float* xa, const float* xb, int Ca, const float* 
 }  // namespace
 
 int feast_ldz(int Cin) { return (H * Cin + 3) / 4 * 4; }
-int feast_ldr(int Cout) { return H * Cout + HP; }
+int feast_ldr(int Cout) { return H * Cout + 2 * HP; }   // [r | dp(12) | dcs(12)]
 
 // algorithmic bytes of one aggregation launch (B_agg with z written out)
 double feast_agg_bytes(int64_t N, int64_t E, int C, int ld_out) {
@@ -517,9 +517,9 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
 
 struct BwdPlan {
   size_t total;
-  float *g, *wf, *dz, *dl, *dpn, *dcs, *rp, *wp;
-  void *tn_ws, *cs_ws;
-  size_t tn_bytes, cs_bytes;
+  float *g, *wf, *dz, *dl, *dpn, *rp, *wp;
+  void* tn_ws;
+  size_t tn_bytes;
 };
 
 static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
@@ -529,14 +529,11 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.dz = a.take<float>((size_t)N * Kp);
   b.dl = a.take<float>((size_t)(Ecap > 0 ? Ecap : 1) * HP);
   b.dpn = a.take<float>((size_t)N * HP);
-  b.dcs = a.take<float>((size_t)N * HP);
   b.rp = a.take<float>((size_t)N * ldr);
   b.wp = a.take<float>((size_t)ldr * Cin);
-  size_t t1 = gemm_tn_ws_bytes(Kp, Cout, N), t2 = gemm_tn_ws_bytes(H, Cin, N);
+  size_t t1 = gemm_tn_ws_bytes(Kp + 1, Cout, N), t2 = gemm_tn_ws_bytes(2 * HP, Cin + 1, N);
   b.tn_bytes = t1 > t2 ? t1 : t2;
   b.tn_ws = a.take<char>(b.tn_bytes);
-  b.cs_bytes = colsum_ws_bytes(N, Cout > HP ? Cout : HP);
-  b.cs_ws = a.take<char>(b.cs_bytes);
   (void)need_dx;
   b.total = align_up(a.off) + 256;
 }
@@ -577,14 +574,14 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_TRY(gemm_nn(g, Cout, b.wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
-  int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn, b.dcs, s);
+  int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,
+                          b.rp + H * Cout + HP, ldr, s);
   prof_end(PROF_ROWPASS, s);
   GEOBI_TRY(rc);
-  // 4. weight gradient dW = z^T g, unpacked into lin.weight layout
-  GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp, Cout, dlin_w, 0, TN_LIN_UNPACK, Cin, Cout, b.tn_ws, b.tn_bytes, s));
-  // 5. bias and c gradients
-  GEOBI_TRY(colsum(g, Cout, N, Cout, dbias, b.cs_ws, b.cs_bytes, s));
-  GEOBI_TRY(colsum(b.dcs, HP, N, H, dc, b.cs_ws, b.cs_bytes, s));
+  // 4. weight + bias gradient in one pass: [z | 1]^T g, unpacked into lin.weight layout / dbias
+  TnOutput ow;
+  ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout;
+  GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, s));
   // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
   feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, b.rp, ldr,
                                                           H * Cout);
@@ -600,10 +597,14 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     if (Cb) { ep1.C1 = dxb; ep1.split = Ca; ep1.ldc1 = Cb; }
     GEOBI_TRY(gemm_nn(b.rp, ldr, b.wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
   }
-  // 7. du = dp^T x   (dp = r'[:, 9*Cout : 9*Cout+9])
-  GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, H, Ca_, du_w, Cin, TN_PLAIN, 0, 0, b.tn_ws, b.tn_bytes, s));
-  if (Cb)
-    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, H, Cb, du_w + Ca, Cin, TN_PLAIN, 0, 0, b.tn_ws, b.tn_bytes, s));
+  // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]
+  TnOutput ou;
+  ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc;
+  GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws, b.tn_bytes, s));
+  if (Cb) {
+    ou.C = du_w + Ca; ou.C2 = nullptr;
+    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, 2 * HP, Cb + 1, -1, Cb, ou, b.tn_ws, b.tn_bytes, s));
+  }
   return 0;
 }
 

@@ -16,7 +16,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;  // block rows
 constexpr int BK = 16;   // k-tile
 
 // A fragment for 32x32x2: lane l holds A[i = l & 31][k = l >> 5]; B fragment: B[k = l >> 5][j = l & 31].
@@ -28,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, float slope,
                                                       float* __restrict__ C1, int split, int ldc1) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  static_assert(WAVES_M * TM * 32 == BM, "block rows");
+  constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int LDA_S = BM + 1;
   constexpr int LDB_S = BN + 4;
@@ -53,9 +52,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   for (int k0 = 0; k0 < K; k0 += BK) {
     // ---- stage A tile [BM x BK] transposed into As[k][m]
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (BM + 63) / 64; ++pass) {
       int row = (tid >> 2) + pass * 64;
       int kq = (tid & 3) * 4;
+      if (BM < 64 && row >= BM) break;
       int gm = m0 + row, gk = k0 + kq;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (gm < M) {
@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
 template <int TI, int TJ>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int64_t M, int I,
-                                                      int J, int tiles_j, int64_t m_per_slice,
-                                                      float* __restrict__ slabs) {
+                                                      int J, int ones_row, int ones_col, int tiles_j,
+                                                      int64_t m_per_slice, float* __restrict__ slabs) {
+  // I, J are the LOGICAL output sizes; row `ones_row` of A^T / column `ones_col` of B read as 1
+  // (bias-style column sums ride along in the same pass); pass -1 to disable.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int ti = tile / tiles_j, tj = tile % tiles_j;
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
       for (int a = 0; a < TI; ++a) {
         int ii = i0 + a * 32 + l31;
-        av[u][a] = (ok && ii < I) ? A[mm * lda + ii] : 0.f;
+        av[u][a] = (ok && ii < I) ? (ii == ones_row ? 1.0f : A[mm * lda + ii]) : 0.f;
       }
 #pragma unroll
       for (int b = 0; b < TJ; ++b) {
         int jj = j0 + b * 32 + l31;
-        bv[u][b] = (ok && jj < J) ? B[mm * ldb + jj] : 0.f;
+        bv[u][b] = (ok && jj < J) ? (jj == ones_col ? 1.0f : B[mm * ldb + jj]) : 0.f;
       }
     }
 #pragma unroll
@@ -225,20 +227,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, int I, int J, float* __restrict__ C,
-                                 int ldc, int mode, int Cin, int Cout) {
+__global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, int I, int J, TnOutput o) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= I * J) return;
   float s = 0.f;
   for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * I * J + idx];
   int i = idx / J, j = idx % J;
-  if (mode == TN_PLAIN) {
-    C[(size_t)i * ldc + j] = s;
-  } else {
+  if (o.mode == TN_PLAIN) {
+    // an implicit ones row / column (always the last one) lands in C2
+    if (o.extra_row && i == I - 1) { if (!(o.extra_col && j == J - 1)) o.C2[j] = s; }
+    else if (o.extra_col && j == J - 1) o.C2[i] = s;
+    else o.C[(size_t)i * o.ldc + j] = s;
+  } else if (o.mode == TN_LIN_UNPACK) {
     // rows are (head h, in-channel k) of the packed weight, columns are out-channels:
-    // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`)
-    int h = i / Cin, k = i % Cin;
-    if (h < GEOBI_H) C[((size_t)h * Cout + j) * Cin + k] = s;
+    // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`); the implicit ones row
+    // (i == I - 1) carries the bias gradient
+    if (i == I - 1) { o.C2[j] = s; return; }
+    int h = i / o.Cin, k = i % o.Cin;
+    if (h < GEOBI_H) o.C[((size_t)h * o.Cout + j) * o.Cin + k] = s;
+  } else {
+    // TN_DU_DC: A = [dp (rows 0..8) | pad | dcs (rows 12..20) | pad], B = [x | 1]
+    //   du[h, col0 + j] = row h, j < J-1 ;   dc[h] = row 12+h, j == J-1
+    if (j < J - 1) { if (i < GEOBI_H) o.C[(size_t)i * o.ldc + j] = s; }
+    else if (o.C2 != nullptr && i >= GEOBI_HP && i < GEOBI_HP + GEOBI_H) o.C2[i - GEOBI_HP] = s;
   }
 }
 
@@ -286,7 +297,7 @@ TnPlan plan_tn(int I, int J, int64_t M) {
   p.tiles_i = cdiv(I, 32 * p.ti);
   p.tiles_j = cdiv(J, 32 * p.tj);
   int tiles = p.tiles_i * p.tiles_j;
-  int64_t want = 4096 / (tiles > 0 ? tiles : 1);     // target ~4096 waves in flight
+  int64_t want = 1536 / (tiles > 0 ? tiles : 1);     // target ~1.5k waves in flight (6 per CU)
   int64_t max_slices = (M + 255) / 256;              // >= 256 nodes per slice
   int64_t sl = want < 4 ? 4 : want;
   if (sl > max_slices) sl = max_slices;
@@ -308,17 +319,26 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   dim3 block(256);
 #define GEOBI_GEMM_LAUNCH(WM, WN, TM_, TN_)                                                                       \
   do {                                                                                                          \
+    constexpr int BM_ = WM * TM_ * 32;                                                                          \
     constexpr int BN_ = WN * TN_ * 32;                                                                          \
-    dim3 grid(cdiv(M, BM), cdiv(N, BN_));                                                                       \
+    dim3 grid(cdiv(M, BM_), cdiv(N, BN_));                                                                      \
     gemm_nn_kernel<WM, WN, TM_, TN_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K, ep.bias,   \
                                                            ep.slope, ep.C1, ep.split, ep.ldc1);                 \
   } while (0)
-  if (N > 64)
-    GEOBI_GEMM_LAUNCH(2, 2, 2, 2);
-  else if (N > 32)
-    GEOBI_GEMM_LAUNCH(2, 2, 2, 1);
-  else
-    GEOBI_GEMM_LAUNCH(4, 1, 1, 1);
+  // Few rows (coarse graph levels): shrink the block tile so the grid still covers the 256 CUs.
+  const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, N > 64 ? 128 : (N > 32 ? 64 : 32));
+  if (big_blocks >= 384) {
+    if (N > 64)
+      GEOBI_GEMM_LAUNCH(2, 2, 2, 2);      // 128 x 128
+    else if (N > 32)
+      GEOBI_GEMM_LAUNCH(2, 2, 2, 1);      // 128 x 64
+    else
+      GEOBI_GEMM_LAUNCH(4, 1, 1, 1);      // 128 x 32
+  } else if (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256) {
+    GEOBI_GEMM_LAUNCH(2, 2, 1, 1);        // 64 x 64
+  } else {
+    GEOBI_GEMM_LAUNCH(1, 4, 1, 1);        // 32 x 128
+  }
 #undef GEOBI_GEMM_LAUNCH
   GEOBI_LAUNCH_OK();
   return 0;
@@ -329,8 +349,8 @@ size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
   return align_up((size_t)p.slices * I * J * sizeof(float)) + 256;
 }
 
-int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc, int mode,
-            int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s) {
+int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
+            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s) {
   if (I <= 0 || J <= 0) return 0;
   TnPlan p = plan_tn(I, J, M);
   Arena a(ws, ws_bytes);
@@ -338,11 +358,13 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
   if (p.tj == 2)
-    gemm_tn_kernel<2, 2><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, p.tiles_j, p.m_per_slice, slabs);
+    gemm_tn_kernel<2, 2><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j, p.m_per_slice,
+                                              slabs);
   else
-    gemm_tn_kernel<2, 1><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, p.tiles_j, p.m_per_slice, slabs);
+    gemm_tn_kernel<2, 1><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j, p.m_per_slice,
+                                              slabs);
   GEOBI_LAUNCH_OK();
-  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.slices, I, J, C, ldc, mode, Cin, Cout);
+  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.slices, I, J, o);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -204,7 +204,7 @@ int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
 }
 
 size_t head_bwd_ws_bytes(int64_t N, int Cin, int K) {
-  size_t t1 = gemm_tn_ws_bytes(K, Cin, N), t2 = gemm_tn_ws_bytes(3, K, N);
+  size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
   size_t c = colsum_ws_bytes(N, K);
   return align_up((size_t)N * 3 * sizeof(float)) + align_up((size_t)N * K * sizeof(float)) +
          align_up(t1 > t2 ? t1 : t2) + align_up(c) + 1024;
@@ -216,7 +216,7 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const f
   Arena a(ws, ws_bytes);
   float* graw = a.take<float>((size_t)N * 3);
   float* dh = a.take<float>((size_t)N * K);
-  size_t t1 = gemm_tn_ws_bytes(K, Cin, N), t2 = gemm_tn_ws_bytes(3, K, N);
+  size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
   size_t tnb = t1 > t2 ? t1 : t2;
   void* tn_ws = a.take<char>(tnb);
   size_t csb = colsum_ws_bytes(N, K);
@@ -224,12 +224,16 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const f
   GEOBI_REQUIRE(a.ok() && ws, "head_bwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
   head_finish_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(gout, raw, nout, mode, dd, (int)N, graw);
   GEOBI_LAUNCH_OK();
-  GEOBI_TRY(gemm_tn(graw, nout, h, K, N, nout, K, dw2, K, TN_PLAIN, 0, 0, tn_ws, tnb, s));
-  GEOBI_TRY(colsum(graw, nout, N, nout, db2, cs_ws, csb, s));
+  // dW2 = graw^T h and db2 = graw^T 1 in one pass (implicit ones column appended to h)
+  TnOutput o2;
+  o2.C = dw2; o2.ldc = K; o2.C2 = db2; o2.extra_col = 1;
+  GEOBI_TRY(gemm_tn(graw, nout, h, K, N, nout, K + 1, -1, K, o2, tn_ws, tnb, s));
   head_dh_kernel<<<cdiv(N * K / 4, 256), 256, 0, s>>>(graw, nout, w2, h, K, slope, N * K, dh);
   GEOBI_LAUNCH_OK();
-  GEOBI_TRY(gemm_tn(dh, K, x, Cin, N, K, Cin, dw1, Cin, TN_PLAIN, 0, 0, tn_ws, tnb, s));
-  GEOBI_TRY(colsum(dh, K, N, K, db1, cs_ws, csb, s));
+  // dW1 = dh^T x and db1 = dh^T 1
+  TnOutput o1;
+  o1.C = dw1; o1.ldc = Cin; o1.C2 = db1; o1.extra_col = 1;
+  GEOBI_TRY(gemm_tn(dh, K, x, Cin, N, K, Cin + 1, -1, Cin, o1, tn_ws, tnb, s));
   if (dx) {
     GemmEpilogue ep;
     GEOBI_TRY(gemm_nn(dh, K, w1, Cin, 0, dx, Cin, (int)N, Cin, K, ep, s));

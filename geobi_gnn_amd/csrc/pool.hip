@@ -99,9 +99,9 @@ __global__ void match_resolve_kernel(const int* __restrict__ prop, int N, int* _
   else atomicAdd(remaining, 1);
 }
 
-__global__ void match_finish_kernel(int N, int* __restrict__ cluster) {
+__global__ void match_finish_kernel(int N, const int* __restrict__ state, int* __restrict__ cluster) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < N && cluster[u] < 0) cluster[u] = u;
+  if (u < N) { int c = state[u]; cluster[u] = c < 0 ? u : c; }
 }
 
 // ----------------------------------------------------------------------------- relabel
@@ -313,26 +313,33 @@ int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s)
   return 0;
 }
 
-size_t match_ws_bytes(int64_t N) { return align_up((size_t)N * sizeof(int)) + 512; }
+size_t match_ws_bytes(int64_t N) { return align_up((size_t)N * sizeof(int)) + 1024; }
 
-// `status[0]` receives the number of nodes still undecided after `rounds` rounds (0 = converged);
-// undecided nodes are closed as singletons so the clustering is always valid.
-int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
-                     int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s) {
-  GEOBI_REQUIRE(N > 0, "match: empty graph");
+// Runs `rounds` proposal rounds.  init != 0 starts from scratch, init == 0 continues from the state
+// in `cluster` (entries < 0 = undecided).  `status[0]` receives the number of nodes still undecided
+// after the last round (0 = converged).  `cluster` keeps the resumable state; `cluster_final`
+// (optional) receives a copy with undecided nodes closed as singletons, i.e. always a valid clustering.
+int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                     int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
+  GEOBI_REQUIRE(N > 0 && rounds > 0, "match: empty graph or no rounds");
   Arena a(ws, ws_bytes);
   int* prop = a.take<int>(N);
+  int* scratch = a.take<int>(64);
   GEOBI_REQUIRE(a.ok() && prop, "match: workspace too small");
-  GEOBI_HIP(hipMemsetAsync(cluster, 0xff, sizeof(int) * N, s));
+  if (init) GEOBI_HIP(hipMemsetAsync(cluster, 0xff, sizeof(int) * N, s));
+  GEOBI_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
   int blocks = cdiv(N, 256);
   for (int r = 0; r < rounds; ++r) {
-    GEOBI_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
     match_propose_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, cluster, (int)N, prop);
-    match_resolve_kernel<<<blocks, 256, 0, s>>>(prop, (int)N, cluster, status);
+    // only the last round's count is reported; earlier rounds count into a scratch word
+    match_resolve_kernel<<<blocks, 256, 0, s>>>(prop, (int)N, cluster, (r == rounds - 1) ? status : scratch);
   }
   GEOBI_LAUNCH_OK();
-  match_finish_kernel<<<blocks, 256, 0, s>>>((int)N, cluster);
-  GEOBI_LAUNCH_OK();
+  if (cluster_final) {
+    match_finish_kernel<<<blocks, 256, 0, s>>>((int)N, cluster, cluster_final);
+    GEOBI_LAUNCH_OK();
+  }
   return 0;
 }
 

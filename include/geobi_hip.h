@@ -86,8 +86,10 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
  *                         (code/net_util.py:226-230):  w_out = w_in + exp(-|x_row - x_col|^2 / 2)
  * geobi_match_heavy_edge: torch_cluster.graclus (code/net_util.py:127,325,353): heavy-edge matching,
  *                         cluster[u] = cluster[v] = min(u, v), unmatched -> own id.  Deterministic
- *                         (greedy in descending edge order); status[0] = nodes left undecided after
- *                         `rounds` proposal rounds (0 = converged; they are closed as singletons).
+ *                         (greedy in descending edge order).  init != 0 starts from scratch, init == 0
+ *                         continues from `cluster` (< 0 = undecided); status[0] = nodes still undecided
+ *                         after `rounds` proposal rounds (0 = converged); cluster_final (optional)
+ *                         receives a copy with the undecided nodes closed as singletons.
  * geobi_relabel_compact : torch_geometric consecutive_cluster (code/net_util.py:128): dense ids by
  *                         ascending cluster id; count[0] = number of clusters (device int32).
  * geobi_segment_csr     : inverse lists segment -> members (ascending), the sorted-segment form of
@@ -104,7 +106,7 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
                           int64_t E, float* w_out, void* stream);
 size_t geobi_match_ws_bytes(int64_t N);
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
-                           int32_t* cluster, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+                           int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_relabel_ws_bytes(int64_t N);
 int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws,
                           size_t ws_bytes, void* stream);

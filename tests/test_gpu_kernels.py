@@ -232,8 +232,9 @@ def test_matching_equals_sorted_greedy(dev, n, m, ties):
         w = (w * 4).floor() / 4
     gr = Graph.from_edge_index(ei.to(dev), n)
     ws = gr.weights_sorted(w.to(dev))
-    cluster, status = net_util.hip_match(gr, ws, rounds=64)
-    assert int(status.item()) == 0
+    cluster, status, state = net_util.hip_match(gr, ws, rounds=3)
+    while int(status.item()) != 0:                       # resume from the saved state until converged
+        cluster, status, state = net_util.hip_match(gr, ws, rounds=3, state=state)
     ref = _greedy_sorted_oracle(n, gr.rowptr_out.cpu().long(), gr.col_out.cpu().long(), ws.cpu())
     assert torch.equal(cluster.cpu().long(), ref)
     # validity (what graclus guarantees): clusters of <= 2 nodes, id = min member, pairs are edges

@@ -147,6 +147,16 @@ before = net.fc_f2.bias.detach().clone()
 opt.step()
 idx = [i for i, (k, _) in enumerate(net.named_parameters()) if k == 'fc_f2.bias'][0]
 assert torch.allclose(net.fc_f2.bias, before - 1.5 * (idx + 1))
+# flat parameters: one optimiser tensor aliasing every module parameter
+from geobi_gnn_amd.parallel import FlatParameters
+net2 = network.DualGNN()
+sd0 = {k: v.clone() for k, v in net2.state_dict().items()}
+fp = FlatParameters(net2)
+assert all(torch.equal(v, sd0[k]) for k, v in net2.state_dict().items())
+fp.bucket.zero()
+net2.fc_v1.bias.grad.add_(1.0)
+torch.optim.SGD(fp.parameters(), lr=0.5).step()
+assert torch.allclose(net2.fc_v1.bias, sd0['fc_v1.bias'] - 0.5) and torch.equal(net2.fc_v2.bias, sd0['fc_v2.bias'])
 sums = reduce_sums([rank + 1.0, 10.0], device)
 assert sums == [3.0, 20.0]
 mine = shard_indices(7, rank, world, seed=3)
