@@ -49,74 +49,105 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   const bool a_vec = ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
   const bool b_vec = ((ldb & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
 
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // ---- stage A tile [BM x BK] transposed into As[k][m]
+  // Software pipeline: the global loads of k-tile t+1 are issued into registers before the MFMAs
+  // of tile t run out of LDS, so HBM/L2 latency overlaps the matrix pipe (single LDS buffer,
+  // two barriers per tile).
+  constexpr int A_PASSES = (BM + 63) / 64;
+  constexpr int B_Q = (BK * BN / 4 + 255) / 256;          // float4 per thread for the B tile
+  float ra[A_PASSES][4];
+  float rb[B_Q][4];
+
+  auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int pass = 0; pass < (BM + 63) / 64; ++pass) {
+    for (int pass = 0; pass < A_PASSES; ++pass) {
       int row = (tid >> 2) + pass * 64;
       int kq = (tid & 3) * 4;
-      if (BM < 64 && row >= BM) break;
       int gm = m0 + row, gk = k0 + kq;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (gm < M) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[pass][i] = 0.f;
+      if (row < BM && gm < M) {
         const float* src = A + (size_t)gm * lda + gk;
         if (a_vec && gk + 3 < K) {
           float4 t = *reinterpret_cast<const float4*>(src);
-          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          ra[pass][0] = t.x; ra[pass][1] = t.y; ra[pass][2] = t.z; ra[pass][3] = t.w;
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (gk + i < K) v[i] = src[i];
+            if (gk + i < K) ra[pass][i] = src[i];
         }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) As[kq + i][row] = v[i];
     }
-    // ---- stage B tile [BK x BN] into Bs[k][n]
-    if (!transB) {
-      constexpr int QPR = BN / 4;            // float4 per tile row
-      constexpr int TOTAL = BK * QPR;        // float4 per tile
-      for (int q = tid; q < TOTAL; q += 256) {
+#pragma unroll
+    for (int qi = 0; qi < B_Q; ++qi) {
+      int q = tid + qi * 256;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[qi][i] = 0.f;
+      if (q >= BK * BN / 4) continue;
+      if (!transB) {
+        constexpr int QPR = BN / 4;
         int kk = q / QPR, nq = (q % QPR) * 4;
         int gk = k0 + kk, gn = n0 + nq;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (gk < K) {
           const float* src = B + (size_t)gk * ldb + gn;
           if (b_vec && gn + 3 < N) {
             float4 t = *reinterpret_cast<const float4*>(src);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            rb[qi][0] = t.x; rb[qi][1] = t.y; rb[qi][2] = t.z; rb[qi][3] = t.w;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (gn + i < N) v[i] = src[i];
+              if (gn + i < N) rb[qi][i] = src[i];
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = v[i];
-      }
-    } else {
-      // B stored [N, K]: read along k, scatter transposed
-      constexpr int TOTAL = BN * (BK / 4);
-      for (int q = tid; q < TOTAL; q += 256) {
+      } else {
         int nn = q >> 2, kq = (q & 3) * 4;
         int gn = n0 + nn, gk = k0 + kq;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (gn < N) {
           const float* src = B + (size_t)gn * ldb + gk;
           if (b_vec && gk + 3 < K) {
             float4 t = *reinterpret_cast<const float4*>(src);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            rb[qi][0] = t.x; rb[qi][1] = t.y; rb[qi][2] = t.z; rb[qi][3] = t.w;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (gk + i < K) v[i] = src[i];
+              if (gk + i < K) rb[qi][i] = src[i];
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = v[i];
       }
     }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int pass = 0; pass < A_PASSES; ++pass) {
+      int row = (tid >> 2) + pass * 64;
+      int kq = (tid & 3) * 4;
+      if (row < BM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[kq + i][row] = ra[pass][i];
+      }
+    }
+#pragma unroll
+    for (int qi = 0; qi < B_Q; ++qi) {
+      int q = tid + qi * 256;
+      if (q >= BK * BN / 4) continue;
+      if (!transB) {
+        constexpr int QPR = BN / 4;
+        int kk = q / QPR, nq = (q % QPR) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = rb[qi][i];
+      } else {
+        int nn = q >> 2, kq = (q & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = rb[qi][i];
+      }
+    }
+  };
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    store_tiles();
     __syncthreads();
+    if (k0 + BK < K) load_tiles(k0 + BK);
     // ---- MFMA over the k-tile
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -168,6 +199,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       int64_t m_per_slice, float* __restrict__ slabs) {
   // I, J are the LOGICAL output sizes; row `ones_row` of A^T / column `ones_col` of B read as 1
   // (bias-style column sums ride along in the same pass); pass -1 to disable.
+  // The 4 waves of a block own 4 consecutive node slices of the SAME output tile and fold their
+  // accumulators through LDS, so one slab is written per block (4x fewer slabs to reduce).
+  __shared__ float red[2][TI * TJ * 16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int ti = tile / tiles_j, tj = tile % tiles_j;
@@ -186,8 +220,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int half = lane >> 5, l31 = lane & 31;
-  for (int64_t m = m_begin; m < m_end; m += 8) {
-    float av[4][TI], bv[4][TJ];
+  float a0[4][TI], b0[4][TJ], a1[4][TI], b1[4][TJ];
+
+  auto load8 = [&](float (&av)[4][TI], float (&bv)[4][TJ], int64_t m) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int64_t mm = m + 2 * u + half;
@@ -203,6 +238,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         bv[u][b] = (ok && jj < J) ? (jj == ones_col ? 1.0f : B[mm * ldb + jj]) : 0.f;
       }
     }
+  };
+  auto mma8 = [&](float (&av)[4][TI], float (&bv)[4][TJ]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -210,19 +247,59 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < TJ; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+  };
+
+  // two register buffers: the loads of the next 8 nodes are in flight while 8 nodes multiply
+  load8(a0, b0, m_begin);
+  for (int64_t m = m_begin; m < m_end; m += 16) {
+    load8(a1, b1, m + 8);
+    mma8(a0, b0);
+    load8(a0, b0, m + 16);
+    mma8(a1, b1);
   }
-  // partial slab [slice][I][J]
-  float* out = slabs + (size_t)slice * I * J;
+
+  // ---- fold the 4 waves: (2,3) -> LDS -> (0,1) add; 1 -> LDS -> 0 adds and writes the slab
+  constexpr int PER = TI * TJ * 16;
+  if (wave >= 2) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 2][((a * TJ + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += red[wave][((a * TJ + b) * 16 + r) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[0][((a * TJ + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  (void)PER;
+  float* out = slabs + (size_t)blockIdx.y * I * J;
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) {
       int jj = j0 + b * 32 + l31;
-      if (jj >= J) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] + red[0][((a * TJ + b) * 16 + r) * 64 + lane];
         int ii = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ii < I) out[(size_t)ii * J + jj] = acc[a][b][r];
+        if (jj < J && ii < I) out[(size_t)ii * J + jj] = v;
       }
     }
 }
@@ -231,6 +308,7 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, in
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= I * J) return;
   float s = 0.f;
+#pragma unroll 8
   for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * I * J + idx];
   int i = idx / J, j = idx % J;
   if (o.mode == TN_PLAIN) {
@@ -306,7 +384,7 @@ TnPlan plan_tn(int I, int J, int64_t M) {
   p.slices = (int)sl;
   p.blocks_y = p.slices / 4;
   int64_t mps = (M + sl - 1) / sl;
-  p.m_per_slice = (mps + 7) / 8 * 8;
+  p.m_per_slice = (mps + 15) / 16 * 16;
   return p;
 }
 
@@ -346,7 +424,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
 
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
   TnPlan p = plan_tn(I, J, M);
-  return align_up((size_t)p.slices * I * J * sizeof(float)) + 256;
+  return align_up((size_t)p.blocks_y * I * J * sizeof(float)) + 256;
 }
 
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
@@ -354,7 +432,7 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   if (I <= 0 || J <= 0) return 0;
   TnPlan p = plan_tn(I, J, M);
   Arena a(ws, ws_bytes);
-  float* slabs = a.take<float>((size_t)p.slices * I * J);
+  float* slabs = a.take<float>((size_t)p.blocks_y * I * J);
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
   if (p.tj == 2)
@@ -364,7 +442,7 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
     gemm_tn_kernel<2, 1><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j, p.m_per_slice,
                                               slabs);
   GEOBI_LAUNCH_OK();
-  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.slices, I, J, o);
+  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
   GEOBI_LAUNCH_OK();
   return 0;
 }

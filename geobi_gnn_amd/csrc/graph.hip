@@ -19,23 +19,32 @@ namespace {
 
 constexpr uint64_t kSentinel = ~0ull;
 
+// Keys are (segment << bits) | neighbour with (1 << bits) > N, so the radix sort only has to look at
+// 2 * bits bits (34 for the 82 k-node level-0 facet graph) instead of 64.  The sentinel (all ones)
+// still sorts last because every valid key is < 2^(2 bits) - 1.
+static inline int key_bits(int64_t N) {
+  int b = 1;
+  while ((1ll << b) <= N) ++b;
+  return b;
+}
+
 __global__ void make_keys_kernel(const int64_t* __restrict__ seg, const int64_t* __restrict__ nbr, int64_t E,
-                                 int drop_self, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                 int drop_self, int bits, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t a = seg[e], b = nbr[e];
-  keys[e] = (drop_self && a == b) ? kSentinel : (((uint64_t)a << 32) | (uint64_t)(uint32_t)b);
+  keys[e] = (drop_self && a == b) ? kSentinel : (((uint64_t)a << bits) | (uint64_t)(uint32_t)b);
   vals[e] = (int32_t)e;
 }
 
 __global__ void expand_keys_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int N,
-                                   int64_t Ecap, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                   int64_t Ecap, int bits, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
   // one thread per node: emits (col << 32 | row) for its CSR segment
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) {
     int rs = rowptr[n], re = rowptr[n + 1];
     for (int e = rs; e < re; ++e) {
-      keys[e] = ((uint64_t)(uint32_t)col[e] << 32) | (uint64_t)(uint32_t)n;
+      keys[e] = ((uint64_t)(uint32_t)col[e] << bits) | (uint64_t)(uint32_t)n;
       vals[e] = e;
     }
   }
@@ -49,19 +58,20 @@ __global__ void expand_keys_kernel(const int32_t* __restrict__ rowptr, const int
   }
 }
 
-__global__ void unpack_sorted_kernel(const uint64_t* __restrict__ keys, int64_t E, int32_t* __restrict__ col) {
+__global__ void unpack_sorted_kernel(const uint64_t* __restrict__ keys, int64_t E, int bits,
+                                     int32_t* __restrict__ col) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   uint64_t k = keys[e];
-  col[e] = (k == kSentinel) ? -1 : (int32_t)(uint32_t)(k & 0xffffffffu);
+  col[e] = (k == kSentinel) ? -1 : (int32_t)(uint32_t)(k & ((1ull << bits) - 1));
 }
 
 // rowptr[n] = first position whose key >= (n << 32)   (n = N gives the valid edge count)
-__global__ void rowptr_search_kernel(const uint64_t* __restrict__ keys, int64_t E, int N,
+__global__ void rowptr_search_kernel(const uint64_t* __restrict__ keys, int64_t E, int N, int bits,
                                      int32_t* __restrict__ rowptr) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n > N) return;
-  uint64_t target = (uint64_t)n << 32;
+  uint64_t target = (uint64_t)n << bits;
   int64_t lo = 0, hi = E;
   while (lo < hi) {
     int64_t mid = (lo + hi) >> 1;
@@ -122,13 +132,15 @@ int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, i
   GEOBI_TRY(carve_sort(a, E, sb));
   GEOBI_REQUIRE(a.ok() && ws != nullptr, "csr_from_coo: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int T = 256;
-  make_keys_kernel<<<cdiv(E, T), T, 0, s>>>(seg, nbr, E, drop_self, sb.k_in, sb.v_in);
+  const int bits = key_bits(N);
+  make_keys_kernel<<<cdiv(E, T), T, 0, s>>>(seg, nbr, E, drop_self, bits, sb.k_in, sb.v_in);
   GEOBI_LAUNCH_OK();
   size_t tb = sb.temp_bytes;
-  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, eid, (size_t)E, 0u, 64u, s, false));
-  unpack_sorted_kernel<<<cdiv(E, T), T, 0, s>>>(sb.k_out, E, col);
+  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, eid, (size_t)E, 0u, (unsigned)(2 * bits), s,
+                                      false));
+  unpack_sorted_kernel<<<cdiv(E, T), T, 0, s>>>(sb.k_out, E, bits, col);
   GEOBI_LAUNCH_OK();
-  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, E, (int)N, rowptr);
+  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, E, (int)N, bits, rowptr);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -148,14 +160,16 @@ int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t 
   GEOBI_REQUIRE(a.ok() && ws != nullptr, "csr_transpose: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int T = 256;
   int blocks = cdiv(N > 0 ? N : 1, T);
-  expand_keys_kernel<<<blocks, T, 0, s>>>(rowptr, col, (int)N, Ecap, sb.k_in, sb.v_in);
+  const int bits = key_bits(N);
+  expand_keys_kernel<<<blocks, T, 0, s>>>(rowptr, col, (int)N, Ecap, bits, sb.k_in, sb.v_in);
   GEOBI_LAUNCH_OK();
   size_t tb = sb.temp_bytes;
-  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, pos_t, (size_t)Ecap, 0u, 64u, s, false));
+  GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, pos_t, (size_t)Ecap, 0u,
+                                      (unsigned)(2 * bits), s, false));
   // low 32 bits of the transposed key hold the original row = the neighbour in the transposed view
-  unpack_sorted_kernel<<<cdiv(Ecap, T), T, 0, s>>>(sb.k_out, Ecap, col_t);
+  unpack_sorted_kernel<<<cdiv(Ecap, T), T, 0, s>>>(sb.k_out, Ecap, bits, col_t);
   GEOBI_LAUNCH_OK();
-  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, Ecap, (int)N, rowptr_t);
+  rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, Ecap, (int)N, bits, rowptr_t);
   GEOBI_LAUNCH_OK();
   if (inv_pos) {
     invert_perm_kernel<<<cdiv(Ecap, T), T, 0, s>>>(pos_t, Ecap, rowptr + N, inv_pos);

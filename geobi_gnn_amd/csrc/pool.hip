@@ -26,6 +26,12 @@ namespace {
 
 constexpr uint64_t kSentinel = ~0ull;
 
+static inline int key_bits(int64_t N) {   // (1 << bits) > N: see graph.hip
+  int b = 1;
+  while ((1ll << b) <= N) ++b;
+  return b;
+}
+
 // ------------------------------------------------------------------------ edge weights
 // 8 lanes per edge, float4 per lane per pass.
 __global__ __launch_bounds__(256) void edge_weight_t10_kernel(const float* __restrict__ x, int C,
@@ -121,20 +127,22 @@ __global__ void relabel_apply_kernel(const int* __restrict__ cluster, const int*
 }
 
 // ------------------------------------------------------------------------ inverse lists
-__global__ void seg_keys_kernel(const int* __restrict__ seg, int64_t n, uint64_t* __restrict__ keys) {
+__global__ void seg_keys_kernel(const int* __restrict__ seg, int64_t n, int bits, uint64_t* __restrict__ keys) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = ((uint64_t)(uint32_t)seg[i] << 32) | (uint64_t)(uint32_t)i;
+  if (i < n) keys[i] = ((uint64_t)(uint32_t)seg[i] << bits) | (uint64_t)(uint32_t)i;
 }
 
-__global__ void seg_unpack_kernel(const uint64_t* __restrict__ keys, int64_t n, int* __restrict__ members) {
+__global__ void seg_unpack_kernel(const uint64_t* __restrict__ keys, int64_t n, int bits,
+                                  int* __restrict__ members) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) members[i] = (int)(uint32_t)(keys[i] & 0xffffffffu);
+  if (i < n) members[i] = (int)(uint32_t)(keys[i] & ((1ull << bits) - 1));
 }
 
-__global__ void seg_ptr_kernel(const uint64_t* __restrict__ keys, int64_t n, int nseg, int* __restrict__ segptr) {
+__global__ void seg_ptr_kernel(const uint64_t* __restrict__ keys, int64_t n, int nseg, int bits,
+                               int* __restrict__ segptr) {
   int sidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (sidx > nseg) return;
-  uint64_t target = (uint64_t)sidx << 32;
+  uint64_t target = (uint64_t)sidx << bits;
   int64_t lo = 0, hi = n;
   while (lo < hi) {
     int64_t mid = (lo + hi) >> 1;
@@ -202,12 +210,12 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __res
 
 // ---------------------------------------------------------------------------- pool_edge
 __global__ void pool_edge_keys_kernel(const int* __restrict__ cnew, const int* __restrict__ row,
-                                      const int* __restrict__ col, int64_t E, uint64_t* __restrict__ keys,
-                                      int* __restrict__ vals) {
+                                      const int* __restrict__ col, int64_t E, int bits,
+                                      uint64_t* __restrict__ keys, int* __restrict__ vals) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int a = cnew[row[e]], b = cnew[col[e]];
-  keys[e] = (a == b) ? kSentinel : (((uint64_t)(uint32_t)a << 32) | (uint64_t)(uint32_t)b);
+  keys[e] = (a == b) ? kSentinel : (((uint64_t)(uint32_t)a << bits) | (uint64_t)(uint32_t)b);
   vals[e] = (int)e;
 }
 
@@ -222,15 +230,15 @@ __global__ void pool_edge_emit_kernel(const uint64_t* __restrict__ keys, const i
                                       const int* __restrict__ head, const int* __restrict__ rank,
                                       const float* __restrict__ w, int64_t E, int* __restrict__ row_c,
                                       int* __restrict__ col_c, float* __restrict__ w_c, uint64_t* __restrict__ ukeys,
-                                      int* __restrict__ count) {
+                                      int* __restrict__ count, int bits) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   if (e == E - 1) *count = rank[e] + head[e];
   if (!head[e]) return;
   uint64_t k = keys[e];
   int o = rank[e];
-  row_c[o] = (int)(uint32_t)(k >> 32);
-  col_c[o] = (int)(uint32_t)(k & 0xffffffffu);
+  row_c[o] = (int)(uint32_t)(k >> bits);
+  col_c[o] = (int)(uint32_t)(k & ((1ull << bits) - 1));
   ukeys[o] = k;
   if (w) {
     // mean of the merged duplicates; fp64 accumulation makes the result independent of the
@@ -243,10 +251,10 @@ __global__ void pool_edge_emit_kernel(const uint64_t* __restrict__ keys, const i
 }
 
 __global__ void pool_edge_rowptr_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ count, int nmax,
-                                        int* __restrict__ rowptr) {
+                                        int bits, int* __restrict__ rowptr) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n > nmax) return;
-  uint64_t target = (uint64_t)n << 32;
+  uint64_t target = (uint64_t)n << bits;
   int lo = 0, hi = *count;
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
@@ -382,11 +390,13 @@ int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, in
   size_t tb = sort_keys_temp_bytes(n);
   void* temp = a.take<char>(tb ? tb : 1);
   GEOBI_REQUIRE(a.ok() && k_in, "segment_csr: workspace too small");
-  seg_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(seg, n, k_in);
+  const int bits = key_bits(n);                 // member index < n
+  const int sbits = key_bits(nseg);
+  seg_keys_kernel<<<cdiv(n, 256), 256, 0, s>>>(seg, n, bits, k_in);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::radix_sort_keys(temp, tb, k_in, k_out, (size_t)n, 0u, 64u, s, false));
-  seg_unpack_kernel<<<cdiv(n, 256), 256, 0, s>>>(k_out, n, members);
-  seg_ptr_kernel<<<cdiv(nseg + 1, 256), 256, 0, s>>>(k_out, n, (int)nseg, segptr);
+  GEOBI_HIP(rocprim::radix_sort_keys(temp, tb, k_in, k_out, (size_t)n, 0u, (unsigned)(bits + sbits), s, false));
+  seg_unpack_kernel<<<cdiv(n, 256), 256, 0, s>>>(k_out, n, bits, members);
+  seg_ptr_kernel<<<cdiv(nseg + 1, 256), 256, 0, s>>>(k_out, n, (int)nseg, bits, segptr);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -459,15 +469,18 @@ int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const
   void* t_scan = a.take<char>(tb_scan ? tb_scan : 1);
   GEOBI_REQUIRE(a.ok() && k_in, "pool_edge: workspace too small (%zu < %zu)", ws_bytes, a.off);
   int blocks = cdiv(E, 256);
-  pool_edge_keys_kernel<<<blocks, 256, 0, s>>>(cnew, row, col, E, k_in, v_in);
+  const int bits = key_bits(nmax);
+  pool_edge_keys_kernel<<<blocks, 256, 0, s>>>(cnew, row, col, E, bits, k_in, v_in);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::radix_sort_pairs(t_sort, tb_sort, k_in, k_out, v_in, v_out, (size_t)E, 0u, 64u, s, false));
+  GEOBI_HIP(rocprim::radix_sort_pairs(t_sort, tb_sort, k_in, k_out, v_in, v_out, (size_t)E, 0u, (unsigned)(2 * bits),
+                                      s, false));
   pool_edge_heads_kernel<<<blocks, 256, 0, s>>>(k_out, E, head);
   GEOBI_LAUNCH_OK();
   GEOBI_HIP(rocprim::exclusive_scan(t_scan, tb_scan, head, rank, 0, (size_t)E, rocprim::plus<int>(), s, false));
-  pool_edge_emit_kernel<<<blocks, 256, 0, s>>>(k_out, v_out, head, rank, w, E, row_c, col_c, w_c, ukeys, count);
+  pool_edge_emit_kernel<<<blocks, 256, 0, s>>>(k_out, v_out, head, rank, w, E, row_c, col_c, w_c, ukeys, count,
+                                               bits);
   GEOBI_LAUNCH_OK();
-  pool_edge_rowptr_kernel<<<cdiv(nmax + 1, 256), 256, 0, s>>>(ukeys, count, (int)nmax, rowptr_c);
+  pool_edge_rowptr_kernel<<<cdiv(nmax + 1, 256), 256, 0, s>>>(ukeys, count, (int)nmax, bits, rowptr_c);
   GEOBI_LAUNCH_OK();
   return 0;
 }
