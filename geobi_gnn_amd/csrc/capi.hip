@@ -90,6 +90,12 @@ int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, in
   return csr_transpose(rowptr, col, N, Ecap, rowptr_t, col_t, pos_t, inv_pos, ws, ws_bytes, S(stream));
 }
 
+int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E,
+                            int32_t* pos_rev, int32_t* flag, void* stream) {
+  NOTNULL(rowptr); NOTNULL(flag);
+  if (E > 0) { NOTNULL(row); NOTNULL(col); NOTNULL(pos_rev); }
+  return csr_reverse_index(rowptr, row, col, E, pos_rev, flag, S(stream));
+}
 int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream) {
   return expand_rowptr(rowptr, N, row, S(stream));
 }
@@ -163,6 +169,19 @@ int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segp
                       size_t ws_bytes, void* stream) {
   NOTNULL(segptr);
   return segment_csr(seg, n, nseg, segptr, members, ws, ws_bytes, S(stream));
+}
+size_t geobi_segment_pairs_ws_bytes(int64_t nseg) { return segment_pairs_ws_bytes(nseg); }
+int geobi_segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_t nseg, int32_t* segptr,
+                            int32_t* members, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(cnew); NOTNULL(raw); NOTNULL(segptr); NOTNULL(members);
+  return segment_csr_pairs(cnew, raw, N, nseg, segptr, members, ws, ws_bytes, S(stream));
+}
+int geobi_segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                              const int32_t* members2, int64_t nseg2, int64_t n_fine, int32_t* segptr12,
+                              int32_t* members12, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(segptr1); NOTNULL(members1); NOTNULL(segptr2); NOTNULL(members2); NOTNULL(segptr12); NOTNULL(members12);
+  return segment_csr_compose(segptr1, members1, segptr2, members2, nseg2, n_fine, segptr12, members12, ws, ws_bytes,
+                             S(stream));
 }
 int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
                           float* out, int32_t* arg, void* stream) {

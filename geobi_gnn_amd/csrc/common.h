@@ -60,6 +60,8 @@ int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, i
                  int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, hipStream_t s);
 int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                   int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, hipStream_t s);
+int csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E, int32_t* pos_rev,
+                      int32_t* flag, hipStream_t s);
 // gemm.hip
 struct GemmEpilogue {
   const float* bias = nullptr;  // [N] added per column
@@ -111,6 +113,12 @@ int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* c
 size_t segment_csr_ws_bytes(int64_t n);
 int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
                 size_t ws_bytes, hipStream_t s);
+size_t segment_pairs_ws_bytes(int64_t nseg);
+int segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_t nseg, int32_t* segptr,
+                      int32_t* members, void* ws, size_t ws_bytes, hipStream_t s);
+int segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                        const int32_t* members2, int64_t nseg2, int64_t n_fine, int32_t* segptr12,
+                        int32_t* members12, void* ws, size_t ws_bytes, hipStream_t s);
 int segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, float* out,
                     int32_t* arg, hipStream_t s);
 int segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,

@@ -16,11 +16,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;   // k-tile
 
 // A fragment for 32x32x2: lane l holds A[i = l & 31][k = l >> 5]; B fragment: B[k = l >> 5][j = l & 31].
 // C/D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int transB,
                                                       float* __restrict__ C, int ldc, int M, int N, int K,
@@ -52,7 +51,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   // Software pipeline: the global loads of k-tile t+1 are issued into registers before the MFMAs
   // of tile t run out of LDS, so HBM/L2 latency overlaps the matrix pipe (single LDS buffer,
   // two barriers per tile).
-  constexpr int A_PASSES = (BM + 63) / 64;
+  constexpr int KQ = BK / 4;                               // float4 per A-tile row
+  constexpr int A_ROWS = 256 / KQ;                         // A rows staged per pass
+  constexpr int A_PASSES = (BM + A_ROWS - 1) / A_ROWS;
   constexpr int B_Q = (BK * BN / 4 + 255) / 256;          // float4 per thread for the B tile
   float ra[A_PASSES][4];
   float rb[B_Q][4];
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int pass = 0; pass < A_PASSES; ++pass) {
-      int row = (tid >> 2) + pass * 64;
-      int kq = (tid & 3) * 4;
+      int row = tid / KQ + pass * A_ROWS;
+      int kq = (tid % KQ) * 4;
       int gm = m0 + row, gk = k0 + kq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) ra[pass][i] = 0.f;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
           }
         }
       } else {
-        int nn = q >> 2, kq = (q & 3) * 4;
+        int nn = q / KQ, kq = (q % KQ) * 4;
         int gn = n0 + nn, gk = k0 + kq;
         if (gn < N) {
           const float* src = B + (size_t)gn * ldb + gk;
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   auto store_tiles = [&]() {
 #pragma unroll
     for (int pass = 0; pass < A_PASSES; ++pass) {
-      int row = (tid >> 2) + pass * 64;
-      int kq = (tid & 3) * 4;
+      int row = tid / KQ + pass * A_ROWS;
+      int kq = (tid % KQ) * 4;
       if (row < BM) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) As[kq + i][row] = ra[pass][i];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = rb[qi][i];
       } else {
-        int nn = q >> 2, kq = (q & 3) * 4;
+        int nn = q / KQ, kq = (q % KQ) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = rb[qi][i];
       }
@@ -370,8 +371,10 @@ struct TnPlan {
 
 TnPlan plan_tn(int I, int J, int64_t M) {
   TnPlan p;
-  p.ti = 2;
-  p.tj = (J > 32) ? 2 : 1;
+  // per-wave tile = (32 TI) x (32 TJ): as large as the shape fills (MFMA work is padded to tiles)
+  int ci = cdiv(I, 32), cj = cdiv(J, 32);
+  p.ti = ci >= 2 ? 2 : 1;
+  p.tj = cj >= 4 ? 2 : cj;              // 1, 2 or 3 column tiles per wave; >= 4 -> pairs
   p.tiles_i = cdiv(I, 32 * p.ti);
   p.tiles_j = cdiv(J, 32 * p.tj);
   int tiles = p.tiles_i * p.tiles_j;
@@ -395,27 +398,28 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   if (M <= 0 || N <= 0) return 0;
   GEOBI_REQUIRE(K > 0, "gemm_nn: K must be positive");
   dim3 block(256);
-#define GEOBI_GEMM_LAUNCH(WM, WN, TM_, TN_)                                                                       \
+#define GEOBI_GEMM_LAUNCH(WM, WN, TM_, TN_, BK_)                                                                    \
   do {                                                                                                          \
     constexpr int BM_ = WM * TM_ * 32;                                                                          \
     constexpr int BN_ = WN * TN_ * 32;                                                                          \
     dim3 grid(cdiv(M, BM_), cdiv(N, BN_));                                                                      \
-    gemm_nn_kernel<WM, WN, TM_, TN_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K, ep.bias,   \
+    gemm_nn_kernel<WM, WN, TM_, TN_, BK_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K,       \
+                                                                ep.bias,                                        \
                                                            ep.slope, ep.C1, ep.split, ep.ldc1);                 \
   } while (0)
   // Few rows (coarse graph levels): shrink the block tile so the grid still covers the 256 CUs.
   const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, N > 64 ? 128 : (N > 32 ? 64 : 32));
   if (big_blocks >= 384) {
     if (N > 64)
-      GEOBI_GEMM_LAUNCH(2, 2, 2, 2);      // 128 x 128
+      GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
     else if (N > 32)
-      GEOBI_GEMM_LAUNCH(2, 2, 2, 1);      // 128 x 64
+      GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32);  // 128 x 64
     else
-      GEOBI_GEMM_LAUNCH(4, 1, 1, 1);      // 128 x 32
+      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);  // 128 x 32
   } else if (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256) {
-    GEOBI_GEMM_LAUNCH(2, 2, 1, 1);        // 64 x 64
+    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);    // 64 x 64
   } else {
-    GEOBI_GEMM_LAUNCH(1, 4, 1, 1);        // 32 x 128
+    GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 32);    // 32 x 128
   }
 #undef GEOBI_GEMM_LAUNCH
   GEOBI_LAUNCH_OK();
@@ -435,12 +439,18 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   float* slabs = a.take<float>((size_t)p.blocks_y * I * J);
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
-  if (p.tj == 2)
-    gemm_tn_kernel<2, 2><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j, p.m_per_slice,
-                                              slabs);
-  else
-    gemm_tn_kernel<2, 1><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j, p.m_per_slice,
-                                              slabs);
+#define GEOBI_TN(TI_, TJ_)                                                                                  \
+  gemm_tn_kernel<TI_, TJ_><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j,       \
+                                                 p.m_per_slice, slabs)
+  switch (p.ti * 10 + p.tj) {
+    case 11: GEOBI_TN(1, 1); break;
+    case 12: GEOBI_TN(1, 2); break;
+    case 13: GEOBI_TN(1, 3); break;
+    case 21: GEOBI_TN(2, 1); break;
+    case 22: GEOBI_TN(2, 2); break;
+    default: GEOBI_TN(2, 3); break;
+  }
+#undef GEOBI_TN
   GEOBI_LAUNCH_OK();
   tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
   GEOBI_LAUNCH_OK();

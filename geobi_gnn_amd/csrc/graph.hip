@@ -87,6 +87,28 @@ __global__ void invert_perm_kernel(const int32_t* __restrict__ pos, int64_t Ecap
   if (e < *count) inv[pos[e]] = (int32_t)e;
 }
 
+// For every edge (i -> j) of a (row, col)-sorted CSR: the position of (j -> i), or -1 (and flag |= 1) if
+// the reverse edge is missing.  For a symmetric graph the transposed CSR is the CSR itself and this
+// index is the edge correspondence the backward pass needs -- no sort.
+__global__ void reverse_index_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ row,
+                                     const int32_t* __restrict__ col, int64_t E, int32_t* __restrict__ pos_rev,
+                                     int32_t* __restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int i = row[e], j = col[e];
+  int lo = rowptr[j], hi = rowptr[j + 1];
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (col[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  if (lo < rowptr[j + 1] && col[lo] == i) {
+    pos_rev[e] = lo;
+  } else {
+    pos_rev[e] = -1;
+    atomicOr(flag, 1);
+  }
+}
+
 struct SortBuffers {
   uint64_t *k_in, *k_out;
   int32_t *v_in, *v_out;
@@ -141,6 +163,15 @@ int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, i
   unpack_sorted_kernel<<<cdiv(E, T), T, 0, s>>>(sb.k_out, E, bits, col);
   GEOBI_LAUNCH_OK();
   rowptr_search_kernel<<<cdiv(N + 1, T), T, 0, s>>>(sb.k_out, E, (int)N, bits, rowptr);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E, int32_t* pos_rev,
+                      int32_t* flag, hipStream_t s) {
+  GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+  if (E <= 0) return 0;
+  reverse_index_kernel<<<cdiv(E, 256), 256, 0, s>>>(rowptr, row, col, E, pos_rev, flag);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -151,6 +151,52 @@ __global__ void seg_ptr_kernel(const uint64_t* __restrict__ keys, int64_t n, int
   segptr[sidx] = (int)lo;
 }
 
+// Inverse lists of a MATCHING (clusters of <= 2 nodes, raw id = smaller member, cnew = dense id):
+// no sort needed -- the representative takes slot 0, its partner slot 1 (members stay ascending).
+__global__ void pair_count_kernel(const int* __restrict__ cnew, const int* __restrict__ raw, int N, int nseg,
+                                  int* __restrict__ cnt) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < nseg) cnt[u] = 1;              // pass 1 of 2 (see launcher): every cluster has its representative
+  (void)cnew; (void)raw; (void)N;
+}
+
+__global__ void pair_mark_kernel(const int* __restrict__ cnew, const int* __restrict__ raw, int N,
+                                 int* __restrict__ cnt) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < N && raw[u] != u) cnt[cnew[u]] = 2;       // exactly one writer per matched cluster
+}
+
+__global__ void pair_fill_kernel(const int* __restrict__ cnew, const int* __restrict__ raw, int N, int nseg,
+                                 int* __restrict__ segptr, int* __restrict__ members) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0) segptr[nseg] = N;
+  if (u < N) members[segptr[cnew[u]] + (raw[u] == u ? 0 : 1)] = u;
+}
+
+// Inverse lists of a composition  fine --(idx1)--> mid --(idx2)--> coarse :
+// members12(C) = concat over m in members2(C) of members1(m)   (fixed order -> deterministic sums)
+__global__ void compose_count_kernel(const int* __restrict__ segptr1, const int* __restrict__ segptr2,
+                                     const int* __restrict__ members2, int nseg2, int* __restrict__ cnt) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nseg2) return;
+  int n = 0;
+  for (int e = segptr2[c]; e < segptr2[c + 1]; ++e) { int m = members2[e]; n += segptr1[m + 1] - segptr1[m]; }
+  cnt[c] = n;
+}
+
+__global__ void compose_fill_kernel(const int* __restrict__ segptr1, const int* __restrict__ members1,
+                                    const int* __restrict__ segptr2, const int* __restrict__ members2, int nseg2,
+                                    int n_fine, int* __restrict__ segptr12, int* __restrict__ members12) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) segptr12[nseg2] = n_fine;
+  if (c >= nseg2) return;
+  int o = segptr12[c];
+  for (int e = segptr2[c]; e < segptr2[c + 1]; ++e) {
+    int m = members2[e];
+    for (int f = segptr1[m]; f < segptr1[m + 1]; ++f) members12[o++] = members1[f];
+  }
+}
+
 // ----------------------------------------------------------------------- segment reduce
 __global__ void segment_max_fwd_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr,
                                        const int* __restrict__ members, int nseg, float* __restrict__ out,
@@ -397,6 +443,45 @@ int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, in
   GEOBI_HIP(rocprim::radix_sort_keys(temp, tb, k_in, k_out, (size_t)n, 0u, (unsigned)(bits + sbits), s, false));
   seg_unpack_kernel<<<cdiv(n, 256), 256, 0, s>>>(k_out, n, bits, members);
   seg_ptr_kernel<<<cdiv(nseg + 1, 256), 256, 0, s>>>(k_out, n, (int)nseg, bits, segptr);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t segment_pairs_ws_bytes(int64_t nseg) {
+  return align_up((size_t)nseg * sizeof(int)) + align_up(scan_temp_bytes<int>(nseg)) + 512;
+}
+
+int segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_t nseg, int32_t* segptr,
+                      int32_t* members, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(N > 0 && nseg > 0, "segment_csr_pairs: empty");
+  Arena a(ws, ws_bytes);
+  int* cnt = a.take<int>(nseg);
+  size_t tb = scan_temp_bytes<int>(nseg);
+  void* temp = a.take<char>(tb ? tb : 1);
+  GEOBI_REQUIRE(a.ok() && cnt, "segment_csr_pairs: workspace too small");
+  pair_count_kernel<<<cdiv(nseg, 256), 256, 0, s>>>(cnew, raw, (int)N, (int)nseg, cnt);
+  pair_mark_kernel<<<cdiv(N, 256), 256, 0, s>>>(cnew, raw, (int)N, cnt);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, segptr, 0, (size_t)nseg, rocprim::plus<int>(), s, false));
+  pair_fill_kernel<<<cdiv(N, 256), 256, 0, s>>>(cnew, raw, (int)N, (int)nseg, segptr, members);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                        const int32_t* members2, int64_t nseg2, int64_t n_fine, int32_t* segptr12,
+                        int32_t* members12, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(nseg2 > 0, "segment_csr_compose: empty");
+  Arena a(ws, ws_bytes);
+  int* cnt = a.take<int>(nseg2);
+  size_t tb = scan_temp_bytes<int>(nseg2);
+  void* temp = a.take<char>(tb ? tb : 1);
+  GEOBI_REQUIRE(a.ok() && cnt, "segment_csr_compose: workspace too small");
+  compose_count_kernel<<<cdiv(nseg2, 256), 256, 0, s>>>(segptr1, segptr2, members2, (int)nseg2, cnt);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, segptr12, 0, (size_t)nseg2, rocprim::plus<int>(), s, false));
+  compose_fill_kernel<<<cdiv(nseg2, 256), 256, 0, s>>>(segptr1, members1, segptr2, members2, (int)nseg2,
+                                                       (int)n_fine, segptr12, members12);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -31,6 +31,7 @@ class Graph(object):
         self._coo64 = None
         self._base = None          # set on the view attached to coo64(): shares the parent's arrays
         self._w_src = self._w_sorted = None
+        self.symmetric = None      # True: in-CSR == out-CSR (checked at level 0, inherited by pooled graphs)
 
     # ------------------------------------------------------------------ construction
     @staticmethod
@@ -50,14 +51,32 @@ class Graph(object):
                L.ptr(eid), L.ptr(ws), ws.numel(), L.stream())
         g.E = int(g.rowptr_out[g.N].item())
         g.col_out, g.eid_out = col[:g.E], eid[:g.E]
+        g._check_symmetric()
         return g
 
+    def _reverse_index(self):
+        dev = self.device
+        pos = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)[:self.E]
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call('geobi_csr_reverse_index', L.ptr(self.rowptr_out), L.ptr(self.ensure_rows()), L.ptr(self.col_out),
+               self.E, L.ptr(pos), L.ptr(flag), L.stream())
+        return pos, flag
+
+    def _check_symmetric(self):
+        """One extra host read at level-0 build time (cached with the graph)."""
+        pos, flag = self._reverse_index()
+        self.symmetric = int(flag.item()) == 0
+        if self.symmetric:
+            self.rowptr_in, self.col_in, self.pos_in = self.rowptr_out, self.col_out, pos
+
     @staticmethod
-    def from_sorted(num_nodes, rowptr, row, col):
-        """Adopt pool_edge's (row, col)-sorted output as the out-CSR."""
+    def from_sorted(num_nodes, rowptr, row, col, symmetric=None):
+        """Adopt pool_edge's (row, col)-sorted output as the out-CSR.  `symmetric` is inherited from
+        the parent level: relabelling both endpoints of a symmetric edge set keeps it symmetric."""
         g = Graph(num_nodes, rowptr.device)
         g.rowptr_out, g.row_out, g.col_out = rowptr, row, col
         g.E = int(col.shape[0])
+        g.symmetric = symmetric
         return g
 
     def ensure_rows(self):
@@ -73,6 +92,9 @@ class Graph(object):
         if self.rowptr_in is None and self._base is not None:
             b = self._base.ensure_in()
             self.rowptr_in, self.col_in, self.pos_in = b.rowptr_in, b.col_in, b.pos_in
+        if self.rowptr_in is None and self.symmetric:
+            pos, _ = self._reverse_index()
+            self.rowptr_in, self.col_in, self.pos_in = self.rowptr_out, self.col_out, pos
         if self.rowptr_in is None:
             dev = self.device
             cap = max(self.E, 1)

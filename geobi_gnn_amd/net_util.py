@@ -21,7 +21,7 @@ from . import ops
 from .data import Data
 from .graph import Graph, graph_of, attach
 
-MATCH_ROUNDS = 10          # measured: 5-8 rounds converge on mesh graphs (icosphere n = 11..32)
+MATCH_ROUNDS = 8           # measured: 5-8 rounds converge on mesh graphs (icosphere n = 11..32); resumed if not
 MATCH_ROUNDS_MAX = 2048
 
 
@@ -97,7 +97,7 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
         cnew, ncount = relabel(cluster32)
         rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
         nc, ec = torch.cat([ncount, ecount]).tolist()
-    coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec])
+    coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec], symmetric=graph.symmetric)
     return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32
 
 
@@ -194,7 +194,7 @@ class PoolingLayer(nn.Module):
         edge_dual = getattr(data, 'edge_dual', None)
         face = getattr(data, 'fv_indices', None)
 
-        clusts, raw = [], []
+        clusts, raw, sidxs = [], [], []
         for _ in range(self.pool_step):
             given = None
             if self.graclus_fn is not None:
@@ -202,7 +202,8 @@ class PoolingLayer(nn.Module):
             cnew, g_c, w_c, cl_raw = _coarsen(g, edge_weight, given)
             raw.append(cl_raw.long())
             clusts.append(cnew)
-            sidx = ops.SegmentIndex(cnew, g_c.N)
+            sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
+            sidxs.append(sidx)
             x = _pool_features(x, sidx, self.pool_type)
             pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
             edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
@@ -212,7 +213,10 @@ class PoolingLayer(nn.Module):
 
         clust = _compose(clusts)
         self.unpooling_indices = clust.long()
-        self._unpool_index = ops.SegmentIndex(clust, g.N)
+        uidx = sidxs[0]
+        for nxt in sidxs[1:]:
+            uidx = ops.SegmentIndex.compose(uidx, nxt, clust)
+        self._unpool_index = uidx
         self.last_clusters = raw
         out = Data(x, g.coo64(), edge_dual=edge_dual, edge_weight=edge_weight, pos=pos, fv_indices=face)
         return out

@@ -84,7 +84,7 @@ def feast_conv(x, graph, lin_w, u_w, c, bias, slope=1.0, x2=None):
 class SegmentIndex(object):
     """Inverse lists ``segment -> members`` of an int32 segment-id vector (sorted, deterministic)."""
 
-    def __init__(self, seg32, nseg):
+    def __init__(self, seg32, nseg, build=True):
         L.require_device(seg32, 'segment ids')
         self.seg = seg32.contiguous()
         self.n = int(seg32.shape[0])
@@ -92,9 +92,30 @@ class SegmentIndex(object):
         dev = seg32.device
         self.segptr = torch.empty(self.nseg + 1, dtype=torch.int32, device=dev)
         self.members = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)[:self.n]
-        ws = L.workspace(L.lib().geobi_segment_csr_ws_bytes(self.n), dev)
-        L.call('geobi_segment_csr', L.ptr(self.seg), self.n, self.nseg, L.ptr(self.segptr), L.ptr(self.members),
-               L.ptr(ws), ws.numel(), L.stream())
+        if build:       # general path: radix sort of (segment, member) keys
+            ws = L.workspace(L.lib().geobi_segment_csr_ws_bytes(self.n), dev)
+            L.call('geobi_segment_csr', L.ptr(self.seg), self.n, self.nseg, L.ptr(self.segptr),
+                   L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
+
+    @staticmethod
+    def from_matching(cnew32, raw32, nseg):
+        """Sort-free lists for a matching (clusters of <= 2 nodes, raw id = smaller member)."""
+        self = SegmentIndex(cnew32, nseg, build=False)
+        raw32 = raw32.contiguous()
+        ws = L.workspace(L.lib().geobi_segment_pairs_ws_bytes(self.nseg), cnew32.device)
+        L.call('geobi_segment_csr_pairs', L.ptr(self.seg), L.ptr(raw32), self.n, self.nseg, L.ptr(self.segptr),
+               L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
+        return self
+
+    @staticmethod
+    def compose(first, second, composed_seg32):
+        """Lists of fine -> coarse for `composed_seg32 = second.seg[first.seg]`."""
+        self = SegmentIndex(composed_seg32, second.nseg, build=False)
+        ws = L.workspace(L.lib().geobi_segment_pairs_ws_bytes(self.nseg), composed_seg32.device)
+        L.call('geobi_segment_csr_compose', L.ptr(first.segptr), L.ptr(first.members), L.ptr(second.segptr),
+               L.ptr(second.members), self.nseg, self.n, L.ptr(self.segptr), L.ptr(self.members), L.ptr(ws),
+               ws.numel(), L.stream())
+        return self
 
 
 class SegmentMaxFn(Function):

@@ -49,6 +49,12 @@ int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_
                        int32_t* rowptr, int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, void* stream);
 int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                         int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream);
+/* geobi_csr_reverse_index: for a (row, col)-sorted CSR, pos_rev[e] = position of the reverse of edge e
+ * (or -1, with flag[0] |= 1, when it is missing).  For a symmetric graph (every mesh graph of the
+ * path, and every pooled graph derived from one) the transposed CSR equals the CSR and pos_rev is the
+ * edge correspondence -- no second sort. */
+int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E,
+                            int32_t* pos_rev, int32_t* flag, void* stream);
 int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream);
 int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream);
 
@@ -113,6 +119,15 @@ int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int3
 size_t geobi_segment_csr_ws_bytes(int64_t n);
 int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
                       size_t ws_bytes, void* stream);
+/* Sort-free inverse lists: _pairs for a matching (clusters of <= 2 nodes, raw id = smaller member, as
+ * graclus / geobi_match_heavy_edge emit, cnew = its dense relabelling); _compose for the lists of a
+ * composed index fine -> mid -> coarse (the `clust2[clust1]` of code/net_util.py:152-156). */
+size_t geobi_segment_pairs_ws_bytes(int64_t nseg);
+int geobi_segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_t nseg, int32_t* segptr,
+                            int32_t* members, void* ws, size_t ws_bytes, void* stream);
+int geobi_segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                              const int32_t* members2, int64_t nseg2, int64_t n_fine, int32_t* segptr12,
+                              int32_t* members12, void* ws, size_t ws_bytes, void* stream);
 int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
                           float* out, int32_t* arg, void* stream);
 int geobi_segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,

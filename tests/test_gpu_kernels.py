@@ -388,3 +388,56 @@ def test_errors_are_loud(dev):
         conv(torch.randn(10, 7, device=dev), torch.zeros(2, 4, dtype=torch.long, device=dev))   # wrong width
     with pytest.raises(L.GeobiError):
         L.call('geobi_gemm_nn', None, 1, None, 1, 0, None, 1, 1, 1, 1, None, 1.0, L.stream())
+
+
+def test_symmetric_graph_reverse_index(dev):
+    """Symmetric graphs skip the transposition sort: in-CSR == out-CSR, pos_in by binary search."""
+    from geobi_gnn_amd.graph import Graph
+    n = 800
+    ei = _sym_graph(n, 3000, seed=21)
+    g = Graph.from_edge_index(ei.to(dev), n)
+    assert g.symmetric is True
+    g.ensure_in()
+    assert g.col_in.data_ptr() == g.col_out.data_ptr()
+    row, col = g.ensure_rows().cpu().long(), g.col_out.cpu().long()
+    key = row * n + col
+    rev = col * n + row
+    expect = torch.searchsorted(key, rev)
+    assert torch.equal(g.pos_in.cpu().long(), expect)
+    # a directed graph is detected and takes the sort path
+    g2 = Graph.from_edge_index(torch.tensor([[0, 1, 2], [1, 2, 0]]).to(dev), 3)
+    assert g2.symmetric is False
+    g2.ensure_in()
+    assert g2.col_in.cpu().tolist() == [2, 0, 1]
+
+
+def test_sort_free_inverse_lists(dev):
+    """from_matching / compose agree with the radix-sort construction."""
+    from geobi_gnn_amd import ops, net_util
+    from geobi_gnn_amd.graph import Graph
+    n = 4000
+    ei = _sym_graph(n, 12000, seed=31, loops=False)
+    gr = Graph.from_edge_index(ei.to(dev), n)
+    w = torch.rand(gr.E, generator=torch.Generator().manual_seed(1)).to(dev)
+    cnew1, g1, w1, raw1 = net_util._coarsen(gr, None)
+    a = ops.SegmentIndex.from_matching(cnew1, raw1, g1.N)
+    b = ops.SegmentIndex(cnew1, g1.N)
+    assert torch.equal(a.segptr, b.segptr) and torch.equal(a.members, b.members)
+    cnew2, g2, _, raw2 = net_util._coarsen(g1, None)
+    a2 = ops.SegmentIndex.from_matching(cnew2, raw2, g2.N)
+    comp = cnew2[cnew1.long()]
+    c_fast = ops.SegmentIndex.compose(a, a2, comp)
+    c_ref = ops.SegmentIndex(comp, g2.N)
+    assert torch.equal(c_fast.segptr, c_ref.segptr)
+    # same member SETS per segment (order inside a segment is fixed but not ascending)
+    sp = c_ref.segptr.cpu().long()
+    seg_of_slot = torch.repeat_interleave(torch.arange(g2.N), sp[1:] - sp[:-1])
+    k_fast = torch.sort(seg_of_slot * n + c_fast.members.cpu().long())[0]
+    k_ref = torch.sort(seg_of_slot * n + c_ref.members.cpu().long())[0]
+    assert torch.equal(k_fast, k_ref)
+    x = torch.randn(g2.N, 8, device=dev, requires_grad=True)
+    gf = torch.randn(n, 8, device=dev)
+    ops.UnpoolFn.apply(x, c_fast).backward(gf)
+    g_fast = x.grad.clone(); x.grad = None
+    ops.UnpoolFn.apply(x, c_ref).backward(gf)
+    assert rel_err(g_fast.cpu(), x.grad.cpu()) < 1e-6
