@@ -237,6 +237,14 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, c
                   S(stream));
 }
 
+size_t geobi_update_position_ws_bytes(int64_t V, int64_t F) { return update_position_ws_bytes(V, F); }
+int geobi_update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval,
+                           const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,
+                           void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(points); NOTNULL(fv); NOTNULL(vf); NOTNULL(normals); NOTNULL(out);
+  return update_position2(points, fv, vf, maxval, normals, dd, V, F, n_iter, out, ws, ws_bytes, S(stream));
+}
+
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
                   int K, const float* bias, float slope, void* stream) {
   NOTNULL(A); NOTNULL(B); NOTNULL(C);

@@ -167,7 +167,71 @@ __global__ void head_dh_kernel(const float* __restrict__ graw, int nout, const f
   *reinterpret_cast<float4*>(dh + t) = s;
 }
 
+// ---------------------------------------------------------------- vertex update (f1)
+__global__ void centroid_kernel(const float* __restrict__ pts, const int* __restrict__ fv, int F,
+                                float* __restrict__ cent) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  V3 c = add(add(ld3(pts + 3 * (size_t)fv[3 * f]), ld3(pts + 3 * (size_t)fv[3 * f + 1])),
+             ld3(pts + 3 * (size_t)fv[3 * f + 2]));
+  cent[3 * (size_t)f] = c.x / 3.0f; cent[3 * (size_t)f + 1] = c.y / 3.0f; cent[3 * (size_t)f + 2] = c.z / 3.0f;
+}
+
+// p_v += 1/max(cnt,1) * sum_{f adj v} n_f (n_f . (c_f - p_v))      (optionally projected on dd_v)
+__global__ void vertex_update_kernel(const float* __restrict__ pts, const float* __restrict__ cent,
+                                     const float* __restrict__ nrm, const int* __restrict__ vf, int maxval,
+                                     const float* __restrict__ dd, int V, float* __restrict__ out) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  V3 p = ld3(pts + 3 * (size_t)v);
+  V3 s = {0.f, 0.f, 0.f};
+  int cnt = 0;
+  for (int a = 0; a < maxval; ++a) {
+    int f = vf[(size_t)v * maxval + a];
+    if (f < 0) continue;
+    ++cnt;
+    V3 n = ld3(nrm + 3 * (size_t)f);
+    float d = dot(n, sub(ld3(cent + 3 * (size_t)f), p));
+    s = add(s, mul(n, d));
+  }
+  float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
+  s = mul(s, inv);
+  if (dd) {
+    V3 d = ld3(dd + 3 * (size_t)v);
+    s = mul(d, dot(s, d));
+  }
+  out[3 * (size_t)v] = p.x + s.x; out[3 * (size_t)v + 1] = p.y + s.y; out[3 * (size_t)v + 2] = p.z + s.z;
+}
+
 }  // namespace
+
+size_t update_position_ws_bytes(int64_t V, int64_t F) {
+  return align_up((size_t)F * 3 * sizeof(float)) + align_up((size_t)V * 3 * sizeof(float)) + 512;
+}
+
+int update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval, const float* normals,
+                     const float* dd, int64_t V, int64_t F, int n_iter, float* out, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
+  GEOBI_REQUIRE(V > 0 && F > 0 && n_iter >= 0, "update_position2: empty mesh");
+  Arena a(ws, ws_bytes);
+  float* cent = a.take<float>((size_t)F * 3);
+  float* tmp = a.take<float>((size_t)V * 3);
+  GEOBI_REQUIRE(a.ok() && ws, "update_position2: workspace too small");
+  // ping-pong so that the LAST iteration lands in `out`
+  const float* src = points;
+  if (n_iter == 0) {
+    GEOBI_HIP(hipMemcpyAsync(out, points, sizeof(float) * V * 3, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  for (int it = 0; it < n_iter; ++it) {
+    float* dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmp;
+    centroid_kernel<<<cdiv(F, 256), 256, 0, s>>>(src, fv, (int)F, cent);
+    vertex_update_kernel<<<cdiv(V, 256), 256, 0, s>>>(src, cent, normals, vf, maxval, dd, (int)V, dst);
+    src = dst;
+  }
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
 
 int face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
                   hipStream_t s) {

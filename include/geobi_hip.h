@@ -165,6 +165,15 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, c
                    float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* ---------------------------------------------------------------- vertex update ----
+ * data_util.update_position2 (code/data_util.py:529-556; called at code/test_dual.py:63-72 after the
+ * network): n_iter Jacobi sweeps  p_v += mean_{f adj v} n_f (n_f . (c_f - p_v)), c_f = face centroid,
+ * vf = padded vertex->face table [V, maxval] with -1 fill, optional projection on depth_direction.   */
+size_t geobi_update_position_ws_bytes(int64_t V, int64_t F);
+int geobi_update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval,
+                           const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- dense helpers ------------
  * Plain fp32 MFMA GEMMs used by the layers above, exported for tests and profiling.            */
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,

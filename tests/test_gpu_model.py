@@ -214,3 +214,82 @@ def test_training_reduces_loss(dev):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0] * 0.8, losses
+
+
+def test_update_position2_matches_reference_fixture(dev):
+    """vertex update on the device vs the fixture computed by the reference's own
+    data_util.update_position2 (tests/golden/pure_functions.npz)."""
+    from geobi_gnn_amd import data_util
+    fx = load_fixture('pure_functions.npz')
+    t = lambda k: torch.from_numpy(fx[k]).to(dev)
+    pts, fv, vf = t('points'), t('faces').long(), t('vf').long()
+    out = data_util.update_position2(pts, fv, vf, t('gt_normal'), n_iter=5)
+    assert rel_err(out.cpu(), torch.from_numpy(fx['update2'])) < OUT_TOL
+    out_d = data_util.update_position2(pts, fv, vf, t('gt_normal'), n_iter=3, depth_direction=t('depth_direction'))
+    assert rel_err(out_d.cpu(), torch.from_numpy(fx['update2_depth'])) < OUT_TOL
+    assert torch.equal(data_util.update_position2(pts, fv, vf, t('gt_normal'), n_iter=0), pts)
+    nrm = data_util.computer_face_normal(pts, fv)
+    assert rel_err(nrm.cpu(), torch.from_numpy(fx['face_normal'])) < OUT_TOL
+
+
+def test_large_scan_inference(dev):
+    """BASELINE config 4: Kinect_Fusion-sized mesh (n = 87, F = 151 380, 2.5 M level-0 edges),
+    single-patch inference + 60-sweep vertex update; properties only (no oracle at this size)."""
+    from geobi_gnn_amd import network, meshgen, infer
+    torch.manual_seed(0)
+    net = network.DualGNN().to(dev).eval()
+    dv, df = meshgen.synthetic_dual_data(87, 0.2, seed=7)
+    assert df.x.shape[0] == 151380
+    meta = dv.meta
+    dvd, dfd = dv.to(dev), df.to(dev)
+    r1 = infer.predict_one(net, dvd, dfd, meta['centroid'], meta['scale'], meta['vf_indices'], n_iter=60,
+                           gt_normals=dfd.y)
+    r2 = infer.predict_one(net, dvd, dfd, meta['centroid'], meta['scale'], meta['vf_indices'], n_iter=60,
+                           gt_normals=dfd.y)
+    assert torch.equal(r1['Np'], r2['Np']) and torch.equal(r1['V_updated'], r2['V_updated'])     # deterministic
+    assert bool(torch.isfinite(r1['V_updated']).all())
+    assert bool(((r1['Np'].norm(dim=1) - 1).abs() < 1e-5).all())
+    assert 0.0 <= r1['angle1'] <= 180.0 and 0.0 <= r1['angle2'] <= 180.0
+    # the input bags were not consumed by the forward (shallow copies)
+    assert dvd.x.shape[1] == 6 and dfd.x.shape[1] == 6
+
+
+def test_angular_error_statistical_parity(dev):
+    """SURVEY 8d metric 2: with each side's OWN matching (HIP: deterministic heavy-edge; oracle: seeded
+    randomised graclus) the mean face-normal angular error vs ground truth agrees after a short training run."""
+    from geobi_gnn_amd import network, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    torch.manual_seed(3)
+    net = network.DualGNN().to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+    train = [[t.to(dev) for t in meshgen.synthetic_dual_data(8, s, seed=10 + i)] for i, s in enumerate((0.1, 0.2, 0.3))]
+    for step in range(45):
+        dv, df = train[step % 3]
+        dv, df = dv.shallow_copy(), df.shallow_copy()
+        opt.zero_grad()
+        vp, npred, _ = net((dv, df))
+        loss = network.dual_loss(network.loss_v(vp, train[step % 3][0].y, 'L1'),
+                                 network.loss_n(npred, train[step % 3][1].y, 'L1'))
+        loss.backward()
+        opt.step()
+    net.eval()
+    ora = R.DualGNN()
+    ora.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    tot_h = tot_o = cnt = 0.0
+    torch.manual_seed(11)
+    for i, s in enumerate((0.1, 0.2, 0.3, 0.2)):
+        dv, df = meshgen.synthetic_dual_data(8, s, seed=50 + i)
+        with torch.no_grad():
+            _, nh, _ = net((dv.to(dev), df.to(dev)))
+            a = P.Data(dv.x.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone())
+            b = P.Data(df.x.clone(), df.edge_index.clone(), edge_weight=df.edge_weight.clone(),
+                       fv_indices=df.fv_indices.clone())
+            _, no, _ = ora((a, b))
+        F_ = df.y.shape[0]
+        tot_h += network.error_n(nh.cpu(), df.y).item() * F_
+        tot_o += R.error_n(no, df.y).item() * F_
+        cnt += F_
+    err_h, err_o = tot_h / cnt, tot_o / cnt
+    print('mean angular error: HIP %.3f deg, oracle %.3f deg' % (err_h, err_o))
+    assert err_h < 60.0 and err_o < 60.0               # training moved both well below the ~90 deg of random weights
+    assert abs(err_h - err_o) < 0.05 * max(err_h, err_o) + 0.5
