@@ -84,10 +84,12 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
             best = {'tag': tag, 'launches': n.value, 'ms': ms.value, 'bytes': by.value}
     lib.geobi_prof_enable(0)
     ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
+    kname = 'feast_aggregate_kernel<%d,%d,0>' % (best['tag'], 3 if best['tag'] in (6, 12) else 4)
+    traffic, traffic_src = pmc_traffic(kname)
     return {
         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-        'kernel': 'feast_aggregate_kernel<%d,%d,0>' % (best['tag'], 3 if best['tag'] in (6, 12) else 4),
+        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+        'kernel': kname,
         'launches': best['launches'], 'avg_us': round(best['ms'] * 1e3 / best['launches'], 2),
         'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
         'all_instantiations': {'launches': total['launches'],
@@ -121,6 +123,18 @@ def host_cores():
 
 def log(msg):
     print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the PMC counters.  They cannot be collected from inside this
+    process (rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE separately); the committed summary of
+    those passes over this same workload is quoted, or null when it is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_feast_aggregate.json')
+    try:
+        k = json.load(open(path))['kernels'][kernel]
+        return k['hbm_bytes_per_launch'], 'profiles/r01_pmc_feast_aggregate.json (tools/pmc_summary.py)'
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(freq=FREQ, timed=3):
