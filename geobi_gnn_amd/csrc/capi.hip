@@ -222,18 +222,18 @@ int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout
 int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
                    int ld_resid, float* h, float* raw, float* out, void* stream) {
-  NOTNULL(x); NOTNULL(w1); NOTNULL(b1); NOTNULL(w2); NOTNULL(b2); NOTNULL(h); NOTNULL(raw); NOTNULL(out);
+  NOTNULL(x); NOTNULL(w1); NOTNULL(b1); NOTNULL(w2); NOTNULL(b2); NOTNULL(raw); NOTNULL(out);
   if (mode == 0) NOTNULL(resid);
   return head_fwd(x, Cin, N, w1, b1, K, w2, b2, nout, slope, mode, dd, resid, ld_resid, h, raw, out, S(stream));
 }
 size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K) { return head_bwd_ws_bytes(N, Cin, K); }
-int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout,
-                   float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
+int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+                   int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
                    float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
                    void* stream) {
-  NOTNULL(x); NOTNULL(w1); NOTNULL(w2); NOTNULL(h); NOTNULL(raw); NOTNULL(gout);
+  NOTNULL(x); NOTNULL(w1); NOTNULL(w2); NOTNULL(raw); NOTNULL(gout);
   NOTNULL(dw1); NOTNULL(db1); NOTNULL(dw2); NOTNULL(db2);
-  return head_bwd(x, Cin, N, w1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, ws, ws_bytes,
+  return head_bwd(x, Cin, N, w1, b1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, ws, ws_bytes,
                   S(stream));
 }
 

@@ -145,8 +145,17 @@ int update_position2(const float* points, const int32_t* fv, const int32_t* vf, 
                      const float* dd, int64_t V, int64_t F, int n_iter, float* out, void* ws, size_t ws_bytes,
                      hipStream_t s);
 size_t head_bwd_ws_bytes(int64_t N, int Cin, int K);
-int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout, float slope,
-             int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
+// head_fused.hip
+bool head_fused_supported(int Cin, int K, int nout);
+int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
+                   int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid, float* raw,
+                   float* out, hipStream_t s);
+size_t head_bwd_fused_ws_bytes(int64_t N);
+int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, int nout,
+                   float slope, const float* graw, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                   void* ws, size_t ws_bytes, hipStream_t s);
+int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2, int nout,
+             float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
              float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace geobi

@@ -255,6 +255,10 @@ int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
   GEOBI_REQUIRE(N > 0 && (K % 256) == 0 && (nout == 1 || nout == 3), "head_fwd: unsupported shape");
   GEOBI_REQUIRE(!(mode == 0 && nout == 1 && dd == nullptr), "head_fwd: force_depth needs depth_direction");
   GEOBI_REQUIRE(!(mode == 1 && nout != 3), "head_fwd: the face head has 3 outputs");
+  if (h == nullptr) {   // fused path: the hidden activation never leaves the matrix-core accumulators
+    GEOBI_REQUIRE(head_fused_supported(Cin, K, nout), "head_fwd: the fused head needs Cin=32, K=1024 (got %d, %d)", Cin, K);
+    return head_fwd_fused(x, N, w1, b1, w2, b2, nout, slope, mode, dd, resid, ld_resid, raw, out, s);
+  }
   GemmEpilogue ep;
   ep.bias = b1;
   ep.slope = slope;
@@ -270,15 +274,27 @@ int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
 size_t head_bwd_ws_bytes(int64_t N, int Cin, int K) {
   size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
   size_t c = colsum_ws_bytes(N, K);
-  return align_up((size_t)N * 3 * sizeof(float)) + align_up((size_t)N * K * sizeof(float)) +
-         align_up(t1 > t2 ? t1 : t2) + align_up(c) + 1024;
+  size_t unfused = align_up((size_t)N * 3 * sizeof(float)) + align_up((size_t)N * K * sizeof(float)) +
+                   align_up(t1 > t2 ? t1 : t2) + align_up(c) + 1024;
+  size_t fused = align_up((size_t)N * 3 * sizeof(float)) + head_bwd_fused_ws_bytes(N) + 1024;
+  return unfused > fused ? unfused : fused;
 }
 
-int head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout, float slope,
-             int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
-             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s) {
+int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2, int nout,
+             float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx,
+             float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s) {
   Arena a(ws, ws_bytes);
   float* graw = a.take<float>((size_t)N * 3);
+  if (h == nullptr) {   // fused path (forward did not save the hidden activation): recompute it in-kernel
+    GEOBI_REQUIRE(head_fused_supported(Cin, K, nout) && dx != nullptr && b1 != nullptr,
+                  "head_bwd: fused path needs Cin=32, K=1024, b1 and dx");
+    size_t fb = head_bwd_fused_ws_bytes(N);
+    void* fws = a.take<char>(fb);
+    GEOBI_REQUIRE(a.ok() && ws, "head_bwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    head_finish_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(gout, raw, nout, mode, dd, (int)N, graw);
+    GEOBI_LAUNCH_OK();
+    return head_bwd_fused(x, N, w1, b1, w2, nout, slope, graw, dx, dw1, db1, dw2, db2, fws, fb, s);
+  }
   float* dh = a.take<float>((size_t)N * K);
   size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
   size_t tnb = t1 > t2 ? t1 : t2;

@@ -1,0 +1,366 @@
+// Fused regression heads: Linear(32 -> 1024) + leaky_relu(0.2) + Linear(1024 -> 1|3) + finish, with
+// the [N, 1024] hidden activation kept in MFMA accumulators -- it never touches HBM, forward or
+// backward (/root/reference/code/network.py:324-343 materialises it twice: 126 MB per 20 k-face
+// mesh, plus the autograd copies).
+//
+// MFMA 32x32x2 fp32 bookkeeping used throughout (lane l: l31 = l & 31, half = l >> 5):
+//   A operand  : A[i = l31][k(s, half)]        B operand : B[k(s, half)][j = l31]
+//   C/D        : column j = l31, row(r, half) = (r & 3) + 8 (r >> 2) + 4 half,  r = 0..15
+// Any pairing k(s, half) works as long as A and B agree.  Two pairings are used:
+//   "contiguous"  k(s, half) = 16 half + s      -- both operands are 16 contiguous floats per lane
+//   "accumulator" k(r, half) = row(r, half)     -- a C/D tile is fed back as the B operand as is
+#include "common.h"
+
+namespace geobi {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CIN = 32;      // head input channels (GNNModule output width)
+constexpr int HID = 1024;    // hidden width
+constexpr int NCHUNK = HID / 32;
+constexpr float kEps = 1e-12f;
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ void load16(const float* __restrict__ p, float (&v)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 t = q[i];
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
+}
+
+// ------------------------------------------------------------------------------ forward
+// one wave = 32 nodes; no LDS, no barriers.
+template <int NOUT>
+__global__ __launch_bounds__(256) void head_fwd_fused_kernel(
+    const float* __restrict__ x, int N, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float slope, int mode,
+    const float* __restrict__ dd, const float* __restrict__ resid, int ld_resid, float* __restrict__ raw,
+    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n0 = (blockIdx.x * 4 + wave) * 32;
+  if (n0 >= N) return;
+  const int row = min(n0 + l31, N - 1);
+  float ax[16];
+  load16(x + (size_t)row * CIN + 16 * half, ax);
+
+  float part[16][NOUT];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) part[r][o] = 0.f;
+
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int j = c * 32 + l31;
+    float bw[16];
+    load16(w1 + (size_t)j * CIN + 16 * half, bw);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], bw[s], acc, 0, 0, 0);
+    const float b1v = b1[j];
+    float w2v[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) w2v[o] = w2[(size_t)o * HID + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float h = acc[r] + b1v;
+      h = h > 0.f ? h : h * slope;
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) part[r][o] = fmaf(h, w2v[o], part[r][o]);
+    }
+  }
+  // sum over the 32 hidden units held by the lanes of each half
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float v = part[r][o];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      part[r][o] = v;
+    }
+  // lane (l31 == r) finishes row(r, half)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (l31 != r) continue;
+    const int node = n0 + acc_row(r, half);
+    if (node >= N) continue;
+    float v[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      v[o] = part[r][o] + b2[o];
+      raw[(size_t)node * NOUT + o] = v[o];
+    }
+    float res[3];
+    if (mode == 0) {
+#pragma unroll
+      for (int cidx = 0; cidx < 3; ++cidx) {
+        float t = (NOUT == 3) ? v[cidx % NOUT] : v[0] * dd[(size_t)node * 3 + cidx];
+        res[cidx] = t + resid[(size_t)node * ld_resid + cidx];
+      }
+    } else {
+      float len = fmaxf(sqrtf(v[0] * v[0] + v[1 % NOUT] * v[1 % NOUT] + v[2 % NOUT] * v[2 % NOUT]), kEps);
+#pragma unroll
+      for (int cidx = 0; cidx < 3; ++cidx) res[cidx] = v[cidx % NOUT] / len;
+    }
+    out[(size_t)node * 3] = res[0]; out[(size_t)node * 3 + 1] = res[1]; out[(size_t)node * 3 + 2] = res[2];
+  }
+}
+
+// ----------------------------------------------------------------------------- backward
+// Persistent blocks of 4 waves; all waves of a block work on the same 32-node tile, wave w owning the
+// hidden chunks {w, w+4, ..., w+28}.  Per chunk: recompute h (16 MFMA), dh in registers, then
+//   dW1^T[k, j] += x^T dh      -- dh (a C/D tile) is the B operand as it stands ("accumulator" pairing)
+//   dx[n, k]    += dh W1       -- dh transposed through a 4.5 KB per-wave LDS tile
+// dW1 / dW2 / db1 partial sums stay in registers across tiles and are written once per block; a
+// second kernel adds the per-block slabs in a fixed order (deterministic, no atomics).
+template <int NOUT>
+__global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
+    const float* __restrict__ x, int N, int ntiles, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, float slope, const float* __restrict__ graw, float* __restrict__ dx,
+    float* __restrict__ p_dw1, float* __restrict__ p_dw2, float* __restrict__ p_db1, float* __restrict__ p_db2) {
+  // The block's running sums live in LDS (all 160 KiB of it: 128 KiB dW1^T tiles, 12 KiB dW2, 4 KiB
+  // db1, 16 KiB transposition / fold scratch); every LDS word has exactly one writer lane, so the
+  // accumulation order is fixed.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sW1 = lds;                                  // [NCHUNK][16][64]
+  float* sW2 = sW1 + NCHUNK * 16 * 64;               // [3][HID]
+  float* sB1 = sW2 + 3 * HID;                        // [HID]
+  float* sT = sB1 + HID;                             // [4][32][32] dh transposition, reused as [4][16][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int i = threadIdx.x; i < NCHUNK * 16 * 64 + 3 * HID + HID; i += 256) lds[i] = 0.f;
+  __syncthreads();
+
+  float db2a[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) db2a[o] = 0.f;
+  float* tw = sT + wave * 1024;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n0 = t * 32;
+    float ax[16], ax2[16], gr[16][NOUT];
+    load16(x + (size_t)min(n0 + l31, N - 1) * CIN + 16 * half, ax);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int node = n0 + acc_row(r, half);
+      const bool ok = node < N;
+      ax2[r] = x[(size_t)(ok ? node : N - 1) * CIN + l31];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        gr[r][o] = ok ? graw[(size_t)node * NOUT + o] : 0.f;
+        db2a[o] += gr[r][o];                                     // every lane of a half holds the same 16 rows
+      }
+    }
+    f32x16 dxacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dxacc[r] = 0.f;
+
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = wave + 4 * cc;
+      const int j = c * 32 + l31;
+      float bw[16];
+      load16(w1 + (size_t)j * CIN + 16 * half, bw);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], bw[s], acc, 0, 0, 0);
+      const float b1v = b1[j];
+      float w2v[NOUT], dw2c[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) { w2v[o] = w2[(size_t)o * HID + j]; dw2c[o] = 0.f; }
+      float dh[16];
+      float db1c = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float hpre = acc[r] + b1v;
+        float hval = hpre > 0.f ? hpre : hpre * slope;
+        float gh = 0.f;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          gh = fmaf(gr[r][o], w2v[o], gh);
+          dw2c[o] = fmaf(gr[r][o], hval, dw2c[o]);
+        }
+        dh[r] = hpre > 0.f ? gh : gh * slope;
+        db1c += dh[r];
+      }
+      // the two halves of a column hold different node rows: fold them, lane < 32 owns the LDS word
+      db1c += __shfl_xor(db1c, 32, 64);
+      if (half == 0) sB1[j] += db1c;
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        float d = dw2c[o] + __shfl_xor(dw2c[o], 32, 64);
+        if (half == 0) sW2[o * HID + j] += d;
+      }
+      // dW1^T chunk tile [k x j]: A = x^T (ax2), B = dh as it stands; added to the block's LDS copy
+      f32x16 tacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tacc[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax2[r], dh[r], tacc, 0, 0, 0);
+      float* w1c = sW1 + (size_t)c * 16 * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w1c[r * 64] += tacc[r];
+      // dx: transpose dh through LDS (XOR-swizzled 16-B slots) -> A operand [node][j]; B = W1 rows
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, half);
+        tw[row * 32 + (l31 ^ ((row & 7) << 2))] = dh[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float ad[16], bq[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = *reinterpret_cast<const float4*>(&tw[l31 * 32 + ((16 * half + 4 * q) ^ ((l31 & 7) << 2))]);
+        ad[4 * q] = v.x; ad[4 * q + 1] = v.y; ad[4 * q + 2] = v.z; ad[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bq[s] = w1[(size_t)(c * 32 + 16 * half + s) * CIN + l31];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dxacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s], bq[s], dxacc, 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // fold the four waves' dx tiles (scratch reused as [4][16][64])
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sT[(wave * 16 + r) * 64 + lane] = dxacc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      float v = sT[(0 * 16 + r) * 64 + lane] + sT[(1 * 16 + r) * 64 + lane] + sT[(2 * 16 + r) * 64 + lane] +
+                sT[(3 * 16 + r) * 64 + lane];
+      const int node = n0 + acc_row(r, half);
+      if (node < N) dx[(size_t)node * CIN + l31] = v;
+    }
+    __syncthreads();
+  }
+
+  // per-block partial sums -> slabs
+  __syncthreads();
+  float* pw = p_dw1 + (size_t)blockIdx.x * (NCHUNK * 16 * 64);
+  for (int i = threadIdx.x; i < NCHUNK * 16 * 64; i += 256) pw[i] = sW1[i];
+  for (int i = threadIdx.x; i < NOUT * HID; i += 256) p_dw2[(size_t)blockIdx.x * NOUT * HID + i] = sW2[i];
+  for (int i = threadIdx.x; i < HID; i += 256) p_db1[(size_t)blockIdx.x * HID + i] = sB1[i];
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float d = db2a[o] + __shfl_xor(db2a[o], 32, 64);
+      if (lane == 0) p_db2[(size_t)blockIdx.x * 4 + o] = d;
+    }
+  }
+}
+
+__global__ void head_bwd_reduce_kernel(const float* __restrict__ p_dw1, const float* __restrict__ p_dw2,
+                                       const float* __restrict__ p_db1, const float* __restrict__ p_db2,
+                                       int blocks, int nout, float* __restrict__ dw1, float* __restrict__ db1,
+                                       float* __restrict__ dw2, float* __restrict__ db2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_dw1 = HID * CIN;
+  if (idx < n_dw1) {
+    // dw1[j, k]  <-  slab element (chunk c = j / 32, reg r, lane) with k = row(r, half), j % 32 = lane & 31
+    const int j = idx / CIN, k = idx % CIN;
+    const int half = (k >> 2) & 1, r = (k & 3) + 4 * (k >> 3), lane = (j & 31) + 32 * half;
+    const size_t off = ((size_t)(j >> 5) * 16 + r) * 64 + lane;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < blocks; ++b) s += p_dw1[(size_t)b * (NCHUNK * 16 * 64) + off];
+    dw1[idx] = s;
+  } else if (idx < n_dw1 + HID) {
+    const int j = idx - n_dw1;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < blocks; ++b) s += p_db1[(size_t)b * HID + j];
+    db1[j] = s;
+  } else if (idx < n_dw1 + HID + nout * HID) {
+    const int e = idx - n_dw1 - HID;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < blocks; ++b) s += p_dw2[(size_t)b * nout * HID + e];
+    dw2[e] = s;
+  } else if (idx < n_dw1 + HID + nout * HID + nout) {
+    const int o = idx - n_dw1 - HID - nout * HID;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += p_db2[(size_t)b * 4 + o];
+    db2[o] = s;
+  }
+}
+
+int bwd_blocks(int64_t N) {
+  int ntiles = cdiv(N, 32);
+  return ntiles < 256 ? ntiles : 256;
+}
+
+}  // namespace
+
+bool head_fused_supported(int Cin, int K, int nout) { return Cin == CIN && K == HID && (nout == 1 || nout == 3); }
+
+int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
+                   int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid, float* raw,
+                   float* out, hipStream_t s) {
+  int blocks = cdiv(N, 128);
+  if (nout == 3)
+    head_fwd_fused_kernel<3><<<blocks, 256, 0, s>>>(x, (int)N, w1, b1, w2, b2, slope, mode, dd, resid, ld_resid, raw,
+                                                    out);
+  else
+    head_fwd_fused_kernel<1><<<blocks, 256, 0, s>>>(x, (int)N, w1, b1, w2, b2, slope, mode, dd, resid, ld_resid, raw,
+                                                    out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t head_bwd_fused_ws_bytes(int64_t N) {
+  size_t b = bwd_blocks(N);
+  return align_up(b * (size_t)NCHUNK * 16 * 64 * sizeof(float)) + align_up(b * 3 * HID * sizeof(float)) +
+         align_up(b * HID * sizeof(float)) + align_up(b * 4 * sizeof(float)) + 1024;
+}
+
+// graw [N, nout] is the gradient w.r.t. the pre-finish head output (head_finish_bwd in geom.hip).
+int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, int nout,
+                   float slope, const float* graw, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                   void* ws, size_t ws_bytes, hipStream_t s) {
+  const int blocks = bwd_blocks(N);
+  Arena a(ws, ws_bytes);
+  float* p_dw1 = a.take<float>((size_t)blocks * NCHUNK * 16 * 64);
+  float* p_dw2 = a.take<float>((size_t)blocks * 3 * HID);
+  float* p_db1 = a.take<float>((size_t)blocks * HID);
+  float* p_db2 = a.take<float>((size_t)blocks * 4);
+  GEOBI_REQUIRE(a.ok() && ws, "head_bwd_fused: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const int ntiles = cdiv(N, 32);
+  constexpr size_t kLds = (size_t)(NCHUNK * 16 * 64 + 3 * HID + HID + 4 * 32 * 32) * sizeof(float);   // 160 KiB
+  static_assert(kLds == 163840, "the backward head kernel uses the whole LDS of a CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GEOBI_HIP(hipFuncSetAttribute((const void*)head_bwd_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kLds));
+    GEOBI_HIP(hipFuncSetAttribute((const void*)head_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kLds));
+    attr_set = true;
+  }
+  if (nout == 3)
+    head_bwd_fused_kernel<3><<<blocks, 256, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
+                                                       p_db1, p_db2);
+  else
+    head_bwd_fused_kernel<1><<<blocks, 256, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
+                                                       p_db1, p_db2);
+  GEOBI_LAUNCH_OK();
+  const int total = HID * CIN + HID + nout * HID + nout;
+  head_bwd_reduce_kernel<<<cdiv(total, 256), 256, 0, s>>>(p_dw1, p_dw2, p_db1, p_db2, blocks, nout, dw1, db1, dw2,
+                                                          db2);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace geobi

@@ -220,7 +220,11 @@ class FaceGeomFn(Function):
 
 
 class HeadFn(Function):
-    """fc2(leaky_relu(fc1 x)) + finish (network.py:324-332 vertex head, :340-343 face head)."""
+    """fc2(leaky_relu(fc1 x)) + finish (network.py:324-332 vertex head, :340-343 face head).
+
+    Fused kernels (Cin = 32, K = 1024): the [N, 1024] hidden activation lives in MFMA accumulators
+    only -- forward and backward (recomputed) -- and is never written to HBM.  Other widths fall
+    back to the generic GEMM path with a materialised hidden tensor."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, mode, dd, resid):
@@ -228,7 +232,8 @@ class HeadFn(Function):
         N, Cin = x.shape
         K, nout = w1.shape[0], w2.shape[0]
         dev = x.device
-        h = torch.empty((N, K), dtype=torch.float32, device=dev)
+        fused = (Cin == 32 and K == 1024)
+        h = None if fused else torch.empty((N, K), dtype=torch.float32, device=dev)
         raw = torch.empty((N, nout), dtype=torch.float32, device=dev)
         out = torch.empty((N, 3), dtype=torch.float32, device=dev)
         dd = None if dd is None else _f32c(dd)
@@ -241,24 +246,26 @@ class HeadFn(Function):
                L.ptr(dd), None if resid is None else resid.data_ptr(), ld_resid, L.ptr(h), L.ptr(raw), L.ptr(out),
                L.stream())
         ctx.mode = mode
-        ctx.has_dd = dd is not None
-        ctx.save_for_backward(x, w1, w2, h, raw, dd if dd is not None else raw)
+        ctx.has_dd, ctx.has_h = dd is not None, h is not None
+        ctx.save_for_backward(x, w1, b1, w2, raw, dd if dd is not None else raw, h if h is not None else raw)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, w1, w2, h, raw, dd = ctx.saved_tensors
+        x, w1, b1, w2, raw, dd, h = ctx.saved_tensors
         if not ctx.has_dd:
             dd = None
+        if not ctx.has_h:
+            h = None
         gout = _f32c(gout)
         N, Cin = x.shape
         K, nout = w1.shape[0], w2.shape[0]
         dev = x.device
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = torch.empty_like(x) if (ctx.needs_input_grad[0] or h is None) else None
         dw1, db1 = torch.empty_like(w1), torch.empty(K, dtype=torch.float32, device=dev)
         dw2, db2 = torch.empty_like(w2), torch.empty(nout, dtype=torch.float32, device=dev)
         ws = L.workspace(L.lib().geobi_head_bwd_ws_bytes(N, Cin, K), dev)
-        L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), K, L.ptr(w2), nout, LEAK, ctx.mode, L.ptr(dd),
-               L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2),
-               L.ptr(ws), ws.numel(), L.stream())
+        L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), L.ptr(b1), K, L.ptr(w2), nout, LEAK, ctx.mode,
+               L.ptr(dd), L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2),
+               L.ptr(db2), L.ptr(ws), ws.numel(), L.stream())
         return dx, dw1, db1, dw2, db2, None, None, None

@@ -154,14 +154,16 @@ int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout
 
 /* ---------------------------------------------------------------- heads --------------------
  * code/network.py:324-332 (vertex head, mode 0: fc2(lrelu(fc1 x)) (* depth_direction) + xyz) and
- * :340-343 (face head, mode 1: F.normalize(fc2(lrelu(fc1 x)), dim=1)).  h [N,K] and raw [N,nout]
- * are saved for the backward.                                                                   */
+ * :340-343 (face head, mode 1: F.normalize(fc2(lrelu(fc1 x)), dim=1)).  raw [N,nout] is saved for the
+ * backward.  h = NULL selects the fused kernels (Cin = 32, K = 1024): the [N, K] hidden activation
+ * stays in the matrix-core accumulators, forward and backward (recomputed), and never reaches HBM;
+ * with a non-NULL h [N,K] the hidden activation is materialised and the generic GEMMs are used.   */
 int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
                    int ld_resid, float* h, float* raw, float* out, void* stream);
 size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K);
-int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, int K, const float* w2, int nout,
-                   float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
+int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
+                   int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
                    float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
                    void* stream);
 
