@@ -55,10 +55,8 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) part[r][o] = 0.f;
 
-  for (int c = 0; c < NCHUNK; ++c) {
+  auto chunk = [&](int c, const float (&bw)[16]) {
     const int j = c * 32 + l31;
-    float bw[16];
-    load16(w1 + (size_t)j * CIN + 16 * half, bw);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -75,6 +73,16 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) part[r][o] = fmaf(h, w2v[o], part[r][o]);
     }
+  };
+  // the next chunk's W1 rows are in flight while the current chunk multiplies
+  const float* w1l = w1 + (size_t)l31 * CIN + 16 * half;
+  float bwa[16], bwb[16];
+  load16(w1l, bwa);
+  for (int c = 0; c < NCHUNK; c += 2) {
+    load16(w1l + (size_t)(c + 1) * 32 * CIN, bwb);
+    chunk(c, bwa);
+    if (c + 2 < NCHUNK) load16(w1l + (size_t)(c + 2) * 32 * CIN, bwa);
+    chunk(c + 1, bwb);
   }
   // sum over the 32 hidden units held by the lanes of each half
 #pragma unroll

@@ -76,32 +76,50 @@ __device__ __forceinline__ bool edge_better(float w1, int a1, int b1, float w2, 
   return b1 < b2;
 }
 
-__global__ void match_propose_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                     const float* __restrict__ w, const int* __restrict__ cluster, int N,
-                                     int* __restrict__ prop) {
+// One kernel per round: node u first commits the outcome of the PREVIOUS round from the proposal
+// array alone (a pair is matched iff the proposals are mutual), then, if still free, proposes to its
+// best free neighbour.  Whether a neighbour w is free is derived the same way (cluster[w] may or may
+// not have been committed yet by w's own thread -- both views agree), so no second "resolve" launch
+// and no grid-wide barrier is needed between the two halves of a round.
+//   prop == -2 : no proposal information (before round 0)      prop == -1 : no free neighbour
+__device__ __forceinline__ bool match_is_free(int w, const int* __restrict__ cluster,
+                                              const int* __restrict__ prop_prev) {
+  if (cluster[w] >= 0) return false;
+  int pw = prop_prev[w];
+  if (pw == -1) return false;                       // closed as a singleton by the previous round
+  return !(pw >= 0 && prop_prev[pw] == w);          // mutually matched in the previous round
+}
+
+__global__ void match_round_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                   const float* __restrict__ w, const int* __restrict__ prop_prev, int N,
+                                   int* __restrict__ cluster, int* __restrict__ prop_next) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  if (cluster[u] >= 0) return;
+  if (cluster[u] >= 0) { prop_next[u] = -1; return; }
+  int pv = prop_prev[u];
+  if (pv == -1) { cluster[u] = u; prop_next[u] = -1; return; }
+  if (pv >= 0 && prop_prev[pv] == u) { cluster[u] = u < pv ? u : pv; prop_next[u] = -1; return; }
   int best = -1, ba = 0, bb = 0;
   float bw = 0.f;
   for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
     int v = col[e];
-    if (v == u || cluster[v] >= 0) continue;
+    if (v == u || !match_is_free(v, cluster, prop_prev)) continue;
     float we = w ? w[e] : 1.0f;
     int a = u < v ? u : v, b = u < v ? v : u;
     if (best < 0 || edge_better(we, a, b, bw, ba, bb)) { best = v; bw = we; ba = a; bb = b; }
   }
-  prop[u] = best;
+  prop_next[u] = best;
 }
 
-__global__ void match_resolve_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
-                                     int* __restrict__ remaining) {
+// commit of the last round + count of nodes that are still undecided
+__global__ void match_commit_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
+                                    int* __restrict__ remaining) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   if (cluster[u] >= 0) return;
   int v = prop[u];
-  if (v < 0) { cluster[u] = u; return; }          // no free neighbour left: singleton
-  if (prop[v] == u) cluster[u] = u < v ? u : v;   // mutual proposal: the pair is matched
+  if (v == -1) { cluster[u] = u; return; }
+  if (v >= 0 && prop[v] == u) cluster[u] = u < v ? u : v;
   else atomicAdd(remaining, 1);
 }
 
@@ -367,7 +385,7 @@ int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s)
   return 0;
 }
 
-size_t match_ws_bytes(int64_t N) { return align_up((size_t)N * sizeof(int)) + 1024; }
+size_t match_ws_bytes(int64_t N) { return 2 * align_up((size_t)N * sizeof(int)) + 1024; }
 
 // Runs `rounds` proposal rounds.  init != 0 starts from scratch, init == 0 continues from the state
 // in `cluster` (entries < 0 = undecided).  `status[0]` receives the number of nodes still undecided
@@ -378,17 +396,20 @@ int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, 
                      hipStream_t s) {
   GEOBI_REQUIRE(N > 0 && rounds > 0, "match: empty graph or no rounds");
   Arena a(ws, ws_bytes);
-  int* prop = a.take<int>(N);
-  int* scratch = a.take<int>(64);
-  GEOBI_REQUIRE(a.ok() && prop, "match: workspace too small");
+  int* prop0 = a.take<int>(N);
+  int* prop1 = a.take<int>(N);
+  GEOBI_REQUIRE(a.ok() && prop0, "match: workspace too small");
   if (init) GEOBI_HIP(hipMemsetAsync(cluster, 0xff, sizeof(int) * N, s));
   GEOBI_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
+  GEOBI_HIP(hipMemsetAsync(prop0, 0xfe, sizeof(int) * N, s));     // 0xfefefefe < -1: "no information"
   int blocks = cdiv(N, 256);
+  int* pp = prop0;
+  int* pn = prop1;
   for (int r = 0; r < rounds; ++r) {
-    match_propose_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, cluster, (int)N, prop);
-    // only the last round's count is reported; earlier rounds count into a scratch word
-    match_resolve_kernel<<<blocks, 256, 0, s>>>(prop, (int)N, cluster, (r == rounds - 1) ? status : scratch);
+    match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, cluster, pn);
+    int* t = pp; pp = pn; pn = t;
   }
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status);
   GEOBI_LAUNCH_OK();
   if (cluster_final) {
     match_finish_kernel<<<blocks, 256, 0, s>>>((int)N, cluster, cluster_final);

@@ -13,6 +13,18 @@ LEAK = 0.2
 HP = 12   # GEOBI_HEAD_STRIDE
 
 
+def _direct_grad(p):
+    """Gradient buffer the kernels may write into directly.
+
+    parallel.GradBucket(direct=True) marks parameters whose ``.grad`` is a persistent view of the
+    flat bucket (zeroed every step, each parameter used once per step).  The backward kernels then
+    store the gradient straight into that view and autograd receives ``None`` -- this removes one
+    accumulate kernel per parameter (76 per step)."""
+    if getattr(p, '_geobi_direct_grad', False) and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         raise L.GeobiError('expected float32, got %s' % t.dtype)
@@ -28,6 +40,7 @@ class FeastConvFn(Function):
     def forward(ctx, xa, xb, lin_w, u_w, c, bias, graph, slope):
         L.require_device(xa, 'x')
         g = graph.ensure_in()
+        ctx.param_refs = (lin_w, u_w, c, bias)
         xa = _f32c(xa)
         xb = None if xb is None else _f32c(xb)
         lin_w, u_w, c, bias = _f32c(lin_w), _f32c(u_w), _f32c(c), _f32c(bias)
@@ -66,14 +79,20 @@ class FeastConvFn(Function):
         need_dx = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
         dxa = torch.empty_like(xa) if need_dx else None
         dxb = torch.empty_like(xb) if (need_dx and xb is not None) else None
-        dlin, du, dc = torch.empty_like(lin_w), torch.empty_like(u_w), torch.empty_like(c)
-        dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
+        direct = [_direct_grad(p_) for p_ in ctx.param_refs]
+        if all(d is not None for d in direct):
+            dlin, du, dc, dbias = direct
+            ret = (None, None, None, None)
+        else:
+            dlin, du, dc = torch.empty_like(lin_w), torch.empty_like(u_w), torch.empty_like(c)
+            dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
+            ret = (dlin, du, dc, dbias)
         ws = L.workspace(L.lib().geobi_feast_bwd_ws_bytes(N, g.E, Cin, Cout), dev)
         L.call('geobi_feast_bwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
                ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
                L.ptr(du), L.ptr(dc), L.ptr(dbias), L.ptr(ws), ws.numel(), L.stream())
-        return dxa, dxb, dlin, du, dc, dbias, None, None
+        return (dxa, dxb) + ret + (None, None)
 
 
 def feast_conv(x, graph, lin_w, u_w, c, bias, slope=1.0, x2=None):
@@ -228,6 +247,7 @@ class HeadFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, mode, dd, resid):
+        ctx.param_refs = (w1, b1, w2, b2)
         x, w1, b1, w2, b2 = _f32c(x), _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
         N, Cin = x.shape
         K, nout = w1.shape[0], w2.shape[0]
@@ -262,10 +282,16 @@ class HeadFn(Function):
         K, nout = w1.shape[0], w2.shape[0]
         dev = x.device
         dx = torch.empty_like(x) if (ctx.needs_input_grad[0] or h is None) else None
-        dw1, db1 = torch.empty_like(w1), torch.empty(K, dtype=torch.float32, device=dev)
-        dw2, db2 = torch.empty_like(w2), torch.empty(nout, dtype=torch.float32, device=dev)
+        direct = [_direct_grad(p_) for p_ in ctx.param_refs]
+        if all(d is not None for d in direct):
+            dw1, db1, dw2, db2 = direct
+            ret = (None, None, None, None)
+        else:
+            dw1, db1 = torch.empty_like(w1), torch.empty(K, dtype=torch.float32, device=dev)
+            dw2, db2 = torch.empty_like(w2), torch.empty(nout, dtype=torch.float32, device=dev)
+            ret = (dw1, db1, dw2, db2)
         ws = L.workspace(L.lib().geobi_head_bwd_ws_bytes(N, Cin, K), dev)
         L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), L.ptr(b1), K, L.ptr(w2), nout, LEAK, ctx.mode,
                L.ptr(dd), L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2),
                L.ptr(db2), L.ptr(ws), ws.numel(), L.stream())
-        return dx, dw1, db1, dw2, db2, None, None, None
+        return (dx,) + ret + (None, None, None)

@@ -46,7 +46,10 @@ class GradBucket(object):
     """All parameter gradients as views of one flat fp32 buffer: zeroing is one memset, the
     data-parallel reduction is one all-reduce, and nothing is copied in or out."""
 
-    def __init__(self, params):
+    def __init__(self, params, direct=False):
+        """direct=True lets the backward kernels store gradients straight into the bucket views
+        (ops._direct_grad); valid while every parameter is used once per step and `zero()` is
+        called before each backward -- the way bench.py and the training loop drive it."""
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -55,6 +58,7 @@ class GradBucket(object):
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            p._geobi_direct_grad = bool(direct)
             off += n
 
     def zero(self):
@@ -78,7 +82,7 @@ class FlatParameters(object):
     ones -- a handful of kernel launches per step -- and the module's own Parameter objects (and
     hence its state_dict) keep working because they alias the flat storage."""
 
-    def __init__(self, module):
+    def __init__(self, module, direct=True):
         params = [p for p in module.parameters() if p.requires_grad]
         flat = torch.cat([p.detach().reshape(-1) for p in params])
         self.flat_param = torch.nn.Parameter(flat)
@@ -87,7 +91,7 @@ class FlatParameters(object):
             n = p.numel()
             p.data = self.flat_param.data[off:off + n].view_as(p)
             off += n
-        self.bucket = GradBucket(params)
+        self.bucket = GradBucket(params, direct=direct)
         self.flat_param.grad = self.bucket.flat
 
     def parameters(self):

@@ -293,3 +293,27 @@ def test_angular_error_statistical_parity(dev):
     print('mean angular error: HIP %.3f deg, oracle %.3f deg' % (err_h, err_o))
     assert err_h < 60.0 and err_o < 60.0               # training moved both well below the ~90 deg of random weights
     assert abs(err_h - err_o) < 0.05 * max(err_h, err_o) + 0.5
+
+
+def test_direct_gradient_writes_match_autograd_accumulation(dev):
+    """parallel.FlatParameters(direct=True): kernels store gradients straight into the flat bucket."""
+    from geobi_gnn_amd import network, meshgen
+    from geobi_gnn_amd.parallel import FlatParameters
+    torch.manual_seed(4)
+    net = network.DualGNN().to(dev)
+    base = [t.to(dev) for t in meshgen.synthetic_dual_data(6, 0.2, seed=9)]
+
+    def grads():
+        dv, df = base[0].shallow_copy(), base[1].shallow_copy()
+        vp, npred, _ = net((dv, df))
+        network.dual_loss(network.loss_v(vp, base[0].y, 'L1'), network.loss_n(npred, base[1].y, 'L1')).backward()
+        return torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+
+    g_ref = grads()
+    flat = FlatParameters(net, direct=True)
+    flat.bucket.zero()
+    g_direct = grads()
+    assert torch.equal(g_ref, g_direct)
+    assert torch.equal(flat.bucket.flat, g_direct)          # the bucket IS the gradient storage
+    flat.bucket.zero()
+    assert torch.equal(grads(), g_ref)                        # and stays valid step after step
