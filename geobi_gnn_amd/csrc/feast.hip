@@ -235,10 +235,23 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
 }
 
 // --------------------------------------------------------------------- backward row pass
+// All-reduce over the G consecutive lanes of a group with DPP lane permutes (one v_add with a DPP
+// source modifier per step, no LDS round trip as ds_bpermute/__shfl would take):
+//   xor 1 / xor 2 inside a quad (quad_perm), quad <-> quad inside 8 lanes (row_half_mirror),
+//   8 <-> 8 inside a 16-lane DPP row (row_mirror); only G = 32 needs one cross-row step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(t);
+}
+
 template <int G>
 __device__ __forceinline__ float group_allreduce(float v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v = dpp_add<0xB1>(v);                              // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v = dpp_add<0x141>(v);       // row_half_mirror
+  if constexpr (G >= 16) v = dpp_add<0x140>(v);      // row_mirror
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64); // across the two 16-lane rows of the group
   return v;
 }
 
