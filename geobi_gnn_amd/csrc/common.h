@@ -68,7 +68,21 @@ struct GemmEpilogue {
   float slope = 1.0f;           // leaky-relu negative slope (1 = identity)
   float* C1 = nullptr;          // optional split output: columns >= split go to C1 (ld = ldc1)
   int split = 0, ldc1 = 0;
+  void* ws = nullptr;           // optional scratch for split-K partial sums (small-M GEMMs)
+  size_t ws_bytes = 0;
+  int fixed_slices = 0;         // > 0: split K exactly this way whatever M is (forward pass: keeps a
+                                // node's result independent of how many other nodes are batched with it)
 };
+// split-K only engages for grids of < 512 small tiles, i.e. M * N < ~2.1 M elements
+static inline size_t gemm_nn_ws_bytes(int64_t M, int N) {
+  return (M * N < (int64_t)2200000) ? align_up((size_t)8 * M * N * sizeof(float)) + 256 : 256;
+}
+// forward GEMM of a FeaSt layer: the split is a function of the layer shape only
+static inline int feast_fwd_slices(int Kp, int Cout) { return Kp >= 1024 ? 4 : ((Kp >= 512 && Cout >= 64) ? 2 : 1); }
+static inline size_t gemm_nn_fixed_ws_bytes(int64_t M, int N, int slices) {
+  size_t b = (size_t)slices * M * N * sizeof(float);
+  return (slices > 1 && b <= ((size_t)256 << 20)) ? align_up(b) + 256 : 256;
+}
 int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
             const GemmEpilogue& ep, hipStream_t s);
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M);

@@ -499,8 +499,8 @@ double feast_agg_bytes(int64_t N, int64_t E, int C, int ld_out) {
 }
 
 size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) {
-  (void)N;
-  return align_up((size_t)feast_ldz(Cin) * Cout * sizeof(float)) + 256;
+  const int Kp = feast_ldz(Cin);
+  return align_up((size_t)Kp * Cout * sizeof(float)) + gemm_nn_fixed_ws_bytes(N, Cout, feast_fwd_slices(Kp, Cout)) + 512;
 }
 
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
@@ -512,6 +512,9 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   const int Kp = feast_ldz(Cin);
   Arena a(ws, ws_bytes);
   float* wf = a.take<float>((size_t)Kp * Cout);
+  const int fwd_slices = feast_fwd_slices(Kp, Cout);
+  const size_t gws = gemm_nn_fixed_ws_bytes(N, Cout, fwd_slices);
+  void* gemm_ws = a.take<char>(gws);
   GEOBI_REQUIRE(a.ok() && wf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
   pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, wf);
   GEOBI_LAUNCH_OK();
@@ -524,6 +527,9 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GemmEpilogue ep;
   ep.bias = bias;
   ep.slope = slope;
+  ep.ws = gemm_ws;
+  ep.ws_bytes = gws;
+  ep.fixed_slices = fwd_slices;      // shape-only split: batching-invariant forward results
   GEOBI_TRY(gemm_nn(z, Kp, wf, Cout, 0, out, Cout, (int)N, Cout, Kp, ep, s));
   return 0;
 }
@@ -531,8 +537,8 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
 struct BwdPlan {
   size_t total;
   float *g, *wf, *dz, *dl, *dpn, *rp, *wp;
-  void* tn_ws;
-  size_t tn_bytes;
+  void *tn_ws, *gemm_ws;
+  size_t tn_bytes, gemm_bytes;
 };
 
 static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
@@ -547,6 +553,9 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   size_t t1 = gemm_tn_ws_bytes(Kp + 1, Cout, N), t2 = gemm_tn_ws_bytes(2 * HP, Cin + 1, N);
   b.tn_bytes = t1 > t2 ? t1 : t2;
   b.tn_ws = a.take<char>(b.tn_bytes);
+  size_t g1 = gemm_nn_ws_bytes(N, Kp), g2 = gemm_nn_ws_bytes(N, Cin);
+  b.gemm_bytes = g1 > g2 ? g1 : g2;
+  b.gemm_ws = a.take<char>(b.gemm_bytes);
   (void)need_dx;
   b.total = align_up(a.off) + 256;
 }
@@ -584,6 +593,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
   GEOBI_LAUNCH_OK();
   GemmEpilogue ep0;
+  ep0.ws = b.gemm_ws;
+  ep0.ws_bytes = b.gemm_bytes;
   GEOBI_TRY(gemm_nn(g, Cout, b.wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
@@ -607,6 +618,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     pack_wprime_kernel<<<cdiv((int64_t)ldr * Cin, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, ldr, b.wp);
     GEOBI_LAUNCH_OK();
     GemmEpilogue ep1;
+    ep1.ws = b.gemm_ws;
+    ep1.ws_bytes = b.gemm_bytes;
     if (Cb) { ep1.C1 = dxb; ep1.split = Ca; ep1.ldc1 = Cb; }
     GEOBI_TRY(gemm_nn(b.rp, ldr, b.wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
   }

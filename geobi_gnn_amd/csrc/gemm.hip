@@ -19,12 +19,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A fragment for 32x32x2: lane l holds A[i = l & 31][k = l >> 5]; B fragment: B[k = l >> 5][j = l & 31].
 // C/D: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int BK>
+// FAST: every operand is 16-B aligned with leading dimensions, K (and N for a non-transposed B)
+// multiples of 4 -- true for every GEMM the model issues.  The staging loads are then branch-free
+// (clamped address + select), which lets the compiler keep them in flight across the MFMA section
+// instead of waiting at the end of each bounds-check branch.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int BK, bool FAST>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int transB,
                                                       float* __restrict__ C, int ldc, int M, int N, int K,
                                                       const float* __restrict__ bias, float slope,
-                                                      float* __restrict__ C1, int split, int ldc1) {
+                                                      float* __restrict__ C1, int split, int ldc1, int k_chunk,
+                                                      float* __restrict__ partial) {
+  // split-K (partial != nullptr): blockIdx.z owns k in [z * k_chunk, (z+1) * k_chunk) and stores the raw
+  // accumulators to partial[z][M][N]; splitk_reduce_kernel adds the slices in order + epilogue.
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -66,7 +73,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
       int gm = m0 + row, gk = k0 + kq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) ra[pass][i] = 0.f;
-      if (row < BM && gm < M) {
+      if constexpr (FAST) {
+        const bool ok = row < BM && gm < M && gk < K;
+        const float* src = A + (size_t)min(gm, M - 1) * lda + min(gk, K - 4);
+        float4 t = *reinterpret_cast<const float4*>(src);
+        ra[pass][0] = ok ? t.x : 0.f; ra[pass][1] = ok ? t.y : 0.f;
+        ra[pass][2] = ok ? t.z : 0.f; ra[pass][3] = ok ? t.w : 0.f;
+      } else if (row < BM && gm < M) {
         const float* src = A + (size_t)gm * lda + gk;
         if (a_vec && gk + 3 < K) {
           float4 t = *reinterpret_cast<const float4*>(src);
@@ -88,7 +101,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
         constexpr int QPR = BN / 4;
         int kk = q / QPR, nq = (q % QPR) * 4;
         int gk = k0 + kk, gn = n0 + nq;
-        if (gk < K) {
+        if constexpr (FAST) {
+          const bool ok = gk < K && gn < N;
+          const float* src = B + (size_t)min(gk, K - 1) * ldb + min(gn, N - 4);
+          float4 t = *reinterpret_cast<const float4*>(src);
+          rb[qi][0] = ok ? t.x : 0.f; rb[qi][1] = ok ? t.y : 0.f;
+          rb[qi][2] = ok ? t.z : 0.f; rb[qi][3] = ok ? t.w : 0.f;
+        } else if (gk < K) {
           const float* src = B + (size_t)gk * ldb + gn;
           if (b_vec && gn + 3 < N) {
             float4 t = *reinterpret_cast<const float4*>(src);
@@ -102,7 +121,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
       } else {
         int nn = q / KQ, kq = (q % KQ) * 4;
         int gn = n0 + nn, gk = k0 + kq;
-        if (gn < N) {
+        if constexpr (FAST) {
+          const bool ok = gn < N && gk < K;
+          const float* src = B + (size_t)min(gn, N - 1) * ldb + min(gk, K - 4);
+          float4 t = *reinterpret_cast<const float4*>(src);
+          rb[qi][0] = ok ? t.x : 0.f; rb[qi][1] = ok ? t.y : 0.f;
+          rb[qi][2] = ok ? t.z : 0.f; rb[qi][3] = ok ? t.w : 0.f;
+        } else if (gn < N) {
           const float* src = B + (size_t)gn * ldb + gk;
           if (b_vec && gk + 3 < K) {
             float4 t = *reinterpret_cast<const float4*>(src);
@@ -144,11 +169,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
     }
   };
 
-  load_tiles(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  const int k_lo = partial ? blockIdx.z * k_chunk : 0;
+  const int k_hi = partial ? min(K, k_lo + k_chunk) : K;
+  load_tiles(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
     store_tiles();
     __syncthreads();
-    if (k0 + BK < K) load_tiles(k0 + BK);
+    if (k0 + BK < k_hi) load_tiles(k0 + BK);
     // ---- MFMA over the k-tile
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -179,6 +206,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
+        if (partial) {
+          partial[((size_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+          continue;
+        }
         float v = acc[i][j][r] + bv;
         v = v > 0.f ? v : v * slope;
         if (C1 != nullptr && col >= split)
@@ -187,6 +218,22 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
           C[(size_t)row * ldc + col] = v;
       }
     }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slices, int M, int N,
+                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, float slope,
+                                     float* __restrict__ C1, int split, int ldc1) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * N) return;
+  float v = 0.f;
+  for (int z = 0; z < slices; ++z) v += partial[(size_t)z * M * N + idx];
+  int row = (int)(idx / N), col = (int)(idx % N);
+  if (bias) v += bias[col];
+  v = v > 0.f ? v : v * slope;
+  if (C1 != nullptr && col >= split)
+    C1[(size_t)row * ldc1 + (col - split)] = v;
+  else
+    C[(size_t)row * ldc + col] = v;
 }
 
 // ------------------------------------------------------------------------------ TN
@@ -398,17 +445,46 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   if (M <= 0 || N <= 0) return 0;
   GEOBI_REQUIRE(K > 0, "gemm_nn: K must be positive");
   dim3 block(256);
+  const bool fast = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((K & 3) == 0) && K >= 4 &&
+                    ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && (transB || ((N & 3) == 0 && N >= 4));
 #define GEOBI_GEMM_LAUNCH(WM, WN, TM_, TN_, BK_)                                                                    \
+  do {                                                                                                          \
+    if (fast) { GEOBI_GEMM_LAUNCH_F(WM, WN, TM_, TN_, BK_, true); } else { GEOBI_GEMM_LAUNCH_F(WM, WN, TM_, TN_, BK_, false); } \
+  } while (0)
+#define GEOBI_GEMM_LAUNCH_F(WM, WN, TM_, TN_, BK_, FAST_)                                                          \
   do {                                                                                                          \
     constexpr int BM_ = WM * TM_ * 32;                                                                          \
     constexpr int BN_ = WN * TN_ * 32;                                                                          \
-    dim3 grid(cdiv(M, BM_), cdiv(N, BN_));                                                                      \
-    gemm_nn_kernel<WM, WN, TM_, TN_, BK_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K,       \
+    dim3 grid(cdiv(M, BM_), cdiv(N, BN_), slices);                                                              \
+    gemm_nn_kernel<WM, WN, TM_, TN_, BK_, FAST_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K, \
                                                                 ep.bias,                                        \
-                                                           ep.slope, ep.C1, ep.split, ep.ldc1);                 \
+                                                           ep.slope, ep.C1, ep.split, ep.ldc1, k_chunk, partial); \
   } while (0)
-  // Few rows (coarse graph levels): shrink the block tile so the grid still covers the 256 CUs.
+  // Few rows (coarse graph levels): shrink the block tile so the grid still covers the 256 CUs, and
+  // split K across blockIdx.z when even the small tiles leave CUs idle.
   const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, N > 64 ? 128 : (N > 32 ? 64 : 32));
+  int slices = 1, k_chunk = K;
+  float* partial = nullptr;
+  int64_t blocks_small = (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256)
+                             ? (int64_t)cdiv(M, 64) * cdiv(N, 64) : (int64_t)cdiv(M, 32) * cdiv(N, 128);
+  if (ep.fixed_slices > 0) {
+    if (ep.fixed_slices > 1 && ep.ws != nullptr) {
+      k_chunk = ((K + ep.fixed_slices - 1) / ep.fixed_slices + 31) / 32 * 32;
+      slices = (K + k_chunk - 1) / k_chunk;
+      if (slices > 1 && (size_t)slices * M * N * sizeof(float) <= ep.ws_bytes) partial = (float*)ep.ws;
+      else { slices = 1; k_chunk = K; }
+    }
+  } else if (big_blocks < 384 && blocks_small < 512 && K >= 256 && ep.ws != nullptr) {
+    int want = (int)((768 + blocks_small - 1) / blocks_small);
+    int maxs = K / 128;
+    slices = want < maxs ? want : maxs;
+    if (slices > 8) slices = 8;
+    if (slices < 1) slices = 1;
+    k_chunk = ((K + slices - 1) / slices + 31) / 32 * 32;       // whole k-tiles per slice
+    slices = (K + k_chunk - 1) / k_chunk;
+    if (slices > 1 && (size_t)slices * M * N * sizeof(float) <= ep.ws_bytes) partial = (float*)ep.ws;
+    else { slices = 1; k_chunk = K; }
+  }
   if (big_blocks >= 384) {
     if (N > 64)
       GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
@@ -422,7 +498,13 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
     GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 32);    // 32 x 128
   }
 #undef GEOBI_GEMM_LAUNCH
+#undef GEOBI_GEMM_LAUNCH_F
   GEOBI_LAUNCH_OK();
+  if (partial) {
+    splitk_reduce_kernel<<<cdiv((int64_t)M * N, 256), 256, 0, s>>>(partial, slices, M, N, C, ldc, ep.bias, ep.slope,
+                                                                  ep.C1, ep.split, ep.ldc1);
+    GEOBI_LAUNCH_OK();
+  }
   return 0;
 }
 
