@@ -18,16 +18,19 @@ def init_distributed(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
+    if use_cuda and os.environ.get('GEOBI_ALL_RANKS_ON_DEVICE0') == '1':
+        local = 0          # rehearsal of the multi-rank path on a 1-GPU box (use with GEOBI_DIST_BACKEND=gloo)
     device = torch.device('cuda', local) if use_cuda else torch.device('cpu')
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        backend = backend or os.environ.get('GEOBI_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
         kw = {}
-        if use_cuda:
+        if use_cuda and backend == 'nccl':
             kw['device_id'] = device
-        dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 
 
