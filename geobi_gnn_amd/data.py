@@ -12,6 +12,7 @@ import torch
 class Data(object):
     def __init__(self, x=None, edge_index=None, **kwargs):
         self.x = x
+        self._graph = None
         self.edge_index = edge_index
         # the reference relies on these reading as None when absent
         # (net_util.py:81 ``data.pos``; :162 ``hasattr(data, 'edge_weight')``)
@@ -21,8 +22,38 @@ class Data(object):
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    # ``edge_index`` of a pooled level is materialised (int64 COO) only when somebody reads it; the
+    # network itself walks the cached CSR (``graph``) and never needs the tensor.
+    @property
+    def edge_index(self):
+        ei = self.__dict__.get('_edge_index')
+        if ei is None and self._graph is not None:
+            ei = self._graph.coo64()
+            self.__dict__['_edge_index'] = ei
+        return ei
+
+    @edge_index.setter
+    def edge_index(self, value):
+        self.__dict__['_edge_index'] = value
+        if value is not None:
+            self._graph = getattr(value, '_geobi_graph', None)
+
+    def graph(self, num_nodes=None):
+        """Cached adjacency (geobi_gnn_amd.graph.Graph) of this level."""
+        if self._graph is None:
+            from .graph import graph_of
+            n = self.num_nodes if num_nodes is None else num_nodes
+            self._graph = graph_of(self.edge_index, n)
+        return self._graph
+
+    def set_graph(self, graph):
+        """Adopt a level whose COO tensor has not been materialised."""
+        self._graph = graph
+        self.__dict__['_edge_index'] = graph._coo64
+
     def keys(self):
-        return [k for k, v in self.__dict__.items() if v is not None and not k.startswith('_')]
+        ks = [k for k, v in self.__dict__.items() if v is not None and not k.startswith('_')]
+        return ks + (['edge_index'] if self.edge_index is not None else [])
 
     @property
     def num_nodes(self):
@@ -30,6 +61,8 @@ class Data(object):
             v = getattr(self, k, None)
             if torch.is_tensor(v):
                 return v.shape[0]
+        if self._graph is not None:
+            return self._graph.N
         if self.edge_index is not None and self.edge_index.numel() > 0:
             return int(self.edge_index.max()) + 1
         return 0
@@ -41,6 +74,10 @@ class Data(object):
     def to(self, device, non_blocking=False):
         out = Data()
         for k, v in self.__dict__.items():
+            if k == '_graph':
+                continue
+            if k == '_edge_index':
+                k, v = 'edge_index', self.edge_index
             if torch.is_tensor(v):
                 v = v.to(device, non_blocking=non_blocking)
             setattr(out, k, v)
@@ -57,7 +94,9 @@ class Data(object):
     def clone(self):
         out = Data()
         for k, v in self.__dict__.items():
-            if k.startswith('_'):
+            if k == '_edge_index':
+                k, v = 'edge_index', self.edge_index
+            elif k.startswith('_'):
                 continue
             setattr(out, k, v.clone() if torch.is_tensor(v) else v)
         return out

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .graph import graph_of
+from .graph import Graph, graph_of
 
 
 class _BareLinear(nn.Module):
@@ -51,12 +51,13 @@ class FeaStConv(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x, edge_index, x2=None, slope=1.0):
-        """x [N, in] (or x | x2 halves), edge_index [2, E] int64 (row = source, col = target).
+        """x [N, in] (or x | x2 halves), edge_index [2, E] int64 (row = source, col = target) or the
+        level's cached ``Graph`` (what GNNModule passes, so pooled levels never build a COO tensor).
 
         ``slope`` fuses the leaky_relu that follows most layers; ``x2`` fuses the skip
         concatenation ``cat((x, x2), 1)`` (network.py:292,298).
         """
-        g = graph_of(edge_index, x.shape[0])
+        g = edge_index if isinstance(edge_index, Graph) else graph_of(edge_index, x.shape[0])
         return ops.feast_conv(x, g, self.lin.weight, self.u.weight, self.c, self.bias, slope=slope, x2=x2)
 
     def __repr__(self):

@@ -29,6 +29,7 @@ class Graph(object):
         self.rowptr_out = self.col_out = self.row_out = self.eid_out = None
         self.rowptr_in = self.col_in = self.pos_in = None
         self._coo64 = None
+        self._view = None
         self._base = None          # set on the view attached to coo64(): shares the parent's arrays
         self._w_src = self._w_sorted = None
         self.symmetric = None      # True: in-CSR == out-CSR (checked at level 0, inherited by pooled graphs)
@@ -109,18 +110,24 @@ class Graph(object):
         return self
 
     # ------------------------------------------------------------------------ views
+    def sorted_view(self):
+        """This level seen through its (row, col)-sorted COO: same arrays, no input permutation."""
+        if self.eid_out is None:
+            return self
+        if self._view is None:
+            view = copy.copy(self)
+            view.eid_out, view._base, view._w_src, view._w_sorted, view._coo64 = None, self, None, None, None
+            view._view = view
+            self._view = view
+        return self._view
+
     def coo64(self):
         """Loop-free COO [2, E] int64 in (row, col)-sorted order -- what the module surface exposes."""
-        if self._coo64 is None:
-            self._coo64 = torch.stack([self.ensure_rows().long(), self.col_out.long()], 0)
-            if self.eid_out is None:
-                attach(self._coo64, self)
-            else:
-                # the sorted COO is its own edge order: attach a view without the permutation
-                view = copy.copy(self)
-                view.eid_out, view._base, view._w_src, view._w_sorted = None, self, None, None
-                attach(self._coo64, view)
-        return self._coo64
+        v = self.sorted_view()
+        if v._coo64 is None:
+            v._coo64 = torch.stack([v.ensure_rows().long(), v.col_out.long()], 0)
+            attach(v._coo64, v)
+        return v._coo64
 
     def weights_sorted(self, edge_weight):
         """Original COO edge weights -> out-CSR order."""

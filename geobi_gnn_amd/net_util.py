@@ -29,7 +29,7 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
-def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None):
+def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None, status=None):
     """Heavy-edge matching on the out-CSR.
 
     Returns (cluster int32 [N] with undecided nodes closed as singletons, status int32 [1] = nodes
@@ -39,7 +39,8 @@ def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None):
     if init:
         state = torch.empty(graph.N, dtype=torch.int32, device=dev)
     cluster = torch.empty(graph.N, dtype=torch.int32, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = L.workspace(L.lib().geobi_match_ws_bytes(graph.N), dev)
     w = None if weight_sorted is None else weight_sorted.contiguous()
     L.call('geobi_match_heavy_edge', L.ptr(graph.rowptr_out), L.ptr(graph.col_out), L.ptr(w), graph.N, rounds,
@@ -47,18 +48,19 @@ def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None):
     return cluster, status, state
 
 
-def relabel(cluster32):
+def relabel(cluster32, count=None):
     """consecutive_cluster: dense ids; returns (cnew int32 [N], count int32 [1] on device)."""
     n = cluster32.shape[0]
     dev = cluster32.device
     cnew = torch.empty(n, dtype=torch.int32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    if count is None:
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = L.workspace(L.lib().geobi_relabel_ws_bytes(n), dev)
     L.call('geobi_relabel_compact', L.ptr(cluster32), n, L.ptr(cnew), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
     return cnew, count
 
 
-def _pool_edge_raw(cnew32, graph, weight_sorted):
+def _pool_edge_raw(cnew32, graph, weight_sorted, count=None):
     """pool_edge on the out-CSR; worst-case sized outputs + device edge count."""
     dev = graph.device
     E, nmax = graph.E, graph.N
@@ -67,7 +69,8 @@ def _pool_edge_raw(cnew32, graph, weight_sorted):
     row_c = torch.empty(cap, dtype=torch.int32, device=dev)
     col_c = torch.empty(cap, dtype=torch.int32, device=dev)
     w_c = None if weight_sorted is None else torch.empty(cap, dtype=torch.float32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    if count is None:
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = L.workspace(L.lib().geobi_pool_edge_ws_bytes(E), dev)
     L.call('geobi_pool_edge', L.ptr(cnew32), L.ptr(graph.ensure_rows()), L.ptr(graph.col_out),
            L.ptr(None if weight_sorted is None else weight_sorted.contiguous()), E, nmax, L.ptr(rowptr_c),
@@ -83,20 +86,23 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
     if cluster32 is None:
         state, total = None, 0
         while True:
-            cluster32, status, state = hip_match(graph, weight_sorted, rounds, state)
+            # one int32[4] holds {undecided, N', E'}: one fill, one device-to-host read per step
+            counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
+            cluster32, _, state = hip_match(graph, weight_sorted, rounds, state, status=counters[0:1])
             total += rounds
-            cnew, ncount = relabel(cluster32)
-            rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
-            undecided, nc, ec = torch.cat([status, ncount, ecount]).tolist()
+            cnew, _ = relabel(cluster32, count=counters[1:2])
+            rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
+            undecided, nc, ec, _ = counters.tolist()
             # rare: proposal chains longer than the rounds run so far -> resume from the saved state.
             # Beyond MATCH_ROUNDS_MAX the undecided nodes stay singletons (still a valid clustering).
             if not undecided or total >= MATCH_ROUNDS_MAX:
                 break
             rounds = min(rounds * 2, MATCH_ROUNDS_MAX - total)
     else:
-        cnew, ncount = relabel(cluster32)
-        rowptr_c, row_c, col_c, w_c, ecount = _pool_edge_raw(cnew, graph, weight_sorted)
-        nc, ec = torch.cat([ncount, ecount]).tolist()
+        counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
+        cnew, _ = relabel(cluster32, count=counters[1:2])
+        rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
+        _, nc, ec, _ = counters.tolist()
     coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec], symmetric=graph.symmetric)
     return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32
 
@@ -108,7 +114,7 @@ def _pool_features(x, sidx, pool_type):
 def _compose(clusts):
     clust = clusts[-1]
     for c in clusts[-2::-1]:
-        clust = clust[c.long()]
+        clust = clust[c]          # int32 index tensors are valid indices
     return clust
 
 
@@ -141,20 +147,26 @@ class PoolingLayer(nn.Module):
             nn.init.xavier_uniform_(self.att_r.data, gain=1.414)
         self.unpooling_indices = None
         self.graclus_fn = None          # optional: callable(edge_index, weight, num_nodes) -> cluster
-        self.last_clusters = None       # raw cluster vectors of the last forward (int64)
+        self._last_clusters32 = None    # raw cluster vectors of the last forward
         self._unpool_index = None
+
+    @property
+    def last_clusters(self):
+        """Raw (pre-relabel) cluster vectors of the last forward, int64 like graclus returns them."""
+        return None if self._last_clusters32 is None else [c.long() for c in self._last_clusters32]
 
     # -- edge weight fed to the matching (no gradient is needed: it only drives integer matching)
     def _get_edge_weight(self, data):
         x = data.x
-        g = graph_of(data.edge_index, x.shape[0])
+        g = data.graph(x.shape[0])
         if g.E == 0:
             return None
         w = getattr(data, 'edge_weight', None)
         if w is not None:
             w = g.weights_sorted(w)
-        # the reference rewrites its input loop-free (net_util.py:166-167)
-        data.edge_index = g.coo64()
+        # the reference rewrites its input loop-free (net_util.py:166-167): same here, with the
+        # (row, col)-sorted COO materialised lazily on first read
+        data.set_graph(g.sorted_view())
         data.edge_weight = w
         t = self.edge_weight_type
         if t == -1:
@@ -190,7 +202,7 @@ class PoolingLayer(nn.Module):
         L.require_device(data.x, 'data.x')
         edge_weight = self._get_edge_weight(data)
         x, pos = data.x, getattr(data, 'pos', None)
-        g = graph_of(data.edge_index, x.shape[0])
+        g = data.graph(x.shape[0])
         edge_dual = getattr(data, 'edge_dual', None)
         face = getattr(data, 'fv_indices', None)
 
@@ -200,7 +212,7 @@ class PoolingLayer(nn.Module):
             if self.graclus_fn is not None:
                 given = _i32(self.graclus_fn(g.coo64(), edge_weight, g.N))
             cnew, g_c, w_c, cl_raw = _coarsen(g, edge_weight, given)
-            raw.append(cl_raw.long())
+            raw.append(cl_raw)
             clusts.append(cnew)
             sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
             sidxs.append(sidx)
@@ -217,8 +229,9 @@ class PoolingLayer(nn.Module):
         for nxt in sidxs[1:]:
             uidx = ops.SegmentIndex.compose(uidx, nxt, clust)
         self._unpool_index = uidx
-        self.last_clusters = raw
-        out = Data(x, g.coo64(), edge_dual=edge_dual, edge_weight=edge_weight, pos=pos, fv_indices=face)
+        self._last_clusters32 = raw
+        out = Data(x, None, edge_dual=edge_dual, edge_weight=edge_weight, pos=pos, fv_indices=face)
+        out.set_graph(g)            # edge_index (int64 COO) materialises on first read
         return out
 
     def unpooling(self, x):

@@ -36,21 +36,25 @@ class GNNModule(nn.Module):
         self.r_conv4 = FeaStConv(64, 32, 9)
 
     def forward(self, data_r1, plot_pool=False):
+        # every level's adjacency is the cached CSR; pooled levels never materialise a COO tensor
+        g1 = data_r1.graph(data_r1.x.shape[0])
         # level 0
-        data_r1.x = self.l_conv1(data_r1.x, data_r1.edge_index, slope=LEAK)
+        data_r1.x = self.l_conv1(data_r1.x, g1, slope=LEAK)
         data_r2 = self.pooling1(data_r1)
+        g2 = data_r2.graph()
         # level 1
-        data_r2.x = self.l_conv2(data_r2.x, data_r2.edge_index, slope=LEAK)
+        data_r2.x = self.l_conv2(data_r2.x, g2, slope=LEAK)
         data_r3 = self.pooling2(data_r2)
+        g3 = data_r3.graph()
         # level 2
-        data_r3.x = self.l_conv3(data_r3.x, data_r3.edge_index, slope=LEAK)
-        data_r3.x = self.l_conv4(data_r3.x, data_r3.edge_index, slope=LEAK)
+        data_r3.x = self.l_conv3(data_r3.x, g3, slope=LEAK)
+        data_r3.x = self.l_conv4(data_r3.x, g3, slope=LEAK)
         # up to level 1: r_conv1 has no activation; the skip cat feeds r_conv2 as two halves
-        up2 = self.r_conv1(self.pooling2.unpooling(data_r3.x), data_r2.edge_index)
-        data_r2.x = self.r_conv2(data_r2.x, data_r2.edge_index, x2=up2, slope=LEAK)
+        up2 = self.r_conv1(self.pooling2.unpooling(data_r3.x), g2)
+        data_r2.x = self.r_conv2(data_r2.x, g2, x2=up2, slope=LEAK)
         # up to level 0
-        up1 = self.r_conv3(self.pooling1.unpooling(data_r2.x), data_r1.edge_index)
-        return self.r_conv4(data_r1.x, data_r1.edge_index, x2=up1, slope=LEAK)
+        up1 = self.r_conv3(self.pooling1.unpooling(data_r2.x), g1)
+        return self.r_conv4(data_r1.x, g1, x2=up1, slope=LEAK)
 
 
 def _fv_index(data_f, num_vertices):
