@@ -59,6 +59,40 @@ void prof_end(int kernel, hipStream_t s) {
   (void)hipEventRecord(g_prof.back().b, s);
 }
 
+// ------------------------------------------------------------------------- side stream
+static int g_overlap = 1;
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
+
+Fork fork_side_stream(hipStream_t main) {
+  Fork f;
+  if (!g_overlap) return f;
+  if (g_side == nullptr) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return f; }
+    if (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming) != hipSuccess) { g_overlap = 0; return f; }
+  }
+  if (hipEventRecord(g_fork_ev, main) != hipSuccess) return f;
+  if (hipStreamWaitEvent(g_side, g_fork_ev, 0) != hipSuccess) return f;
+  f.side = g_side;
+  f.join = g_join_ev;
+  return f;
+}
+
+int side_wait_main(const Fork& f, hipStream_t main) {
+  if (f.side == nullptr) return 0;
+  GEOBI_HIP(hipEventRecord(g_fork_ev, main));
+  GEOBI_HIP(hipStreamWaitEvent(f.side, g_fork_ev, 0));
+  return 0;
+}
+
+int join_side_stream(const Fork& f, hipStream_t main) {
+  if (f.side == nullptr) return 0;
+  GEOBI_HIP(hipEventRecord(f.join, f.side));
+  GEOBI_HIP(hipStreamWaitEvent(main, f.join, 0));
+  return 0;
+}
+
 }  // namespace geobi
 
 using namespace geobi;
@@ -261,6 +295,11 @@ int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, i
   o.C = C;
   o.ldc = ldc;
   return gemm_tn(A, lda, B, ldb, M, I, J, -1, -1, o, ws, ws_bytes, S(stream));
+}
+
+int geobi_set_overlap(int enable) {
+  g_overlap = enable ? 1 : 0;
+  return 0;
 }
 
 int geobi_prof_enable(int kernel) {

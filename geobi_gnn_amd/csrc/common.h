@@ -53,6 +53,15 @@ enum ProfKernel { PROF_NONE = 0, PROF_AGG_FWD = 1, PROF_AGG_BWD = 2, PROF_ROWPAS
 void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag);
 void prof_end(int kernel, hipStream_t s);
 
+// ---- side stream for work that is off the critical path of a backward call (weight gradients)
+struct Fork {
+  hipStream_t side = nullptr;   // nullptr: overlap disabled, run on the caller's stream
+  hipEvent_t join = nullptr;
+};
+Fork fork_side_stream(hipStream_t main);       // side stream waits for everything enqueued on `main` so far
+int join_side_stream(const Fork& f, hipStream_t main);   // `main` waits for the side stream
+int side_wait_main(const Fork& f, hipStream_t main);     // side stream waits for `main` as of now
+
 // ---- launchers implemented across the translation units (all enqueue on `s`, never sync)
 // graph.hip
 size_t csr_ws_bytes(int64_t E, int64_t N);

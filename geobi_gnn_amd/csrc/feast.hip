@@ -537,8 +537,8 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
 struct BwdPlan {
   size_t total;
   float *g, *wf, *dz, *dl, *dpn, *rp, *wp;
-  void *tn_ws, *gemm_ws;
-  size_t tn_bytes, gemm_bytes;
+  void *tn_ws, *tn_ws2, *gemm_ws;
+  size_t tn_bytes, tn_bytes2, gemm_bytes;
 };
 
 static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
@@ -550,9 +550,10 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.dpn = a.take<float>((size_t)N * HP);
   b.rp = a.take<float>((size_t)N * ldr);
   b.wp = a.take<float>((size_t)ldr * Cin);
-  size_t t1 = gemm_tn_ws_bytes(Kp + 1, Cout, N), t2 = gemm_tn_ws_bytes(2 * HP, Cin + 1, N);
-  b.tn_bytes = t1 > t2 ? t1 : t2;
+  b.tn_bytes = gemm_tn_ws_bytes(Kp + 1, Cout, N);           // [z | 1]^T g   (side stream)
   b.tn_ws = a.take<char>(b.tn_bytes);
+  b.tn_bytes2 = gemm_tn_ws_bytes(2 * HP, Cin + 1, N);        // [dp | dcs]^T [x | 1]
+  b.tn_ws2 = a.take<char>(b.tn_bytes2);
   size_t g1 = gemm_nn_ws_bytes(N, Kp), g2 = gemm_nn_ws_bytes(N, Cin);
   b.gemm_bytes = g1 > g2 ? g1 : g2;
   b.gemm_ws = a.take<char>(b.gemm_bytes);
@@ -589,6 +590,13 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     GEOBI_LAUNCH_OK();
     g = b.g;
   }
+  // 2'. weight + bias gradient [z | 1]^T g: needs only z and g, nothing downstream needs it -> side stream
+  Fork fk = fork_side_stream(s);
+  {
+    TnOutput ow;
+    ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout;
+    GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, fk.side ? fk.side : s));
+  }
   // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
   pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
   GEOBI_LAUNCH_OK();
@@ -602,14 +610,23 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
                           b.rp + H * Cout + HP, ldr, s);
   prof_end(PROF_ROWPASS, s);
   GEOBI_TRY(rc);
-  // 4. weight + bias gradient in one pass: [z | 1]^T g, unpacked into lin.weight layout / dbias
-  TnOutput ow;
-  ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout;
-  GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, s));
   // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
   feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, b.rp, ldr,
                                                           H * Cout);
   GEOBI_LAUNCH_OK();
+  // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]; needs the row
+  //    pass and dp_gather only -> also off the critical path (side stream, after an event on main)
+  {
+    GEOBI_TRY(side_wait_main(fk, s));
+    hipStream_t ss = fk.side ? fk.side : s;
+    TnOutput ou;
+    ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc;
+    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws2, b.tn_bytes2, ss));
+    if (Cb) {
+      ou.C = du_w + Ca; ou.C2 = nullptr;
+      GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, 2 * HP, Cb + 1, -1, Cb, ou, b.tn_ws2, b.tn_bytes2, ss));
+    }
+  }
   if (dxa != nullptr) {
     prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);
     rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, s);
@@ -623,14 +640,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     if (Cb) { ep1.C1 = dxb; ep1.split = Ca; ep1.ldc1 = Cb; }
     GEOBI_TRY(gemm_nn(b.rp, ldr, b.wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
   }
-  // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]
-  TnOutput ou;
-  ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc;
-  GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws, b.tn_bytes, s));
-  if (Cb) {
-    ou.C = du_w + Ca; ou.C2 = nullptr;
-    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, 2 * HP, Cb + 1, -1, Cb, ou, b.tn_ws, b.tn_bytes, s));
-  }
+  // the side stream's results (and its scratch) are handed back before the call returns
+  GEOBI_TRY(join_side_stream(fk, s));
   return 0;
 }
 

@@ -184,6 +184,12 @@ size_t geobi_gemm_tn_ws_bytes(int I, int J, int64_t M);
 int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- concurrency --------------
+ * Weight-gradient GEMMs are off the critical path of a backward call; by default they run on a
+ * library-owned non-blocking HIP stream, forked from and joined back into `stream` INSIDE the call
+ * (event wait on both ends), so the caller's stream semantics are unchanged.  0 disables it.     */
+int geobi_set_overlap(int enable);
+
 /* ---------------------------------------------------------------- measurement --------------
  * When enabled, the selected kernel family is bracketed with HIP events on its launch stream
  * (kernel: 1 = FeaSt aggregation forward, 2 = transposed aggregation backward, 3 = backward row
