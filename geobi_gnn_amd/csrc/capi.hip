@@ -271,6 +271,18 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const fl
                   S(stream));
 }
 
+size_t geobi_row_loss_ws_bytes(int64_t n) { return row_loss_ws_bytes(n); }
+int geobi_row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int kind, float scale, float* out,
+                       void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(a); NOTNULL(b); NOTNULL(out);
+  return row_loss_fwd(a, b, w, n, kind, scale, out, ws, ws_bytes, S(stream));
+}
+int geobi_row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
+                       float scale, float* ga, void* stream) {
+  NOTNULL(a); NOTNULL(b); NOTNULL(gout); NOTNULL(ga);
+  return row_loss_bwd(a, b, w, gout, n, kind, scale, ga, S(stream));
+}
+
 size_t geobi_update_position_ws_bytes(int64_t V, int64_t F) { return update_position_ws_bytes(V, F); }
 int geobi_update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval,
                            const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,

@@ -163,6 +163,11 @@ int face_geom_bwd(const float* verts, const int32_t* fv, const float* g, int64_t
 int head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
              const float* b2, int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid,
              float* h, float* raw, float* out, hipStream_t s);
+size_t row_loss_ws_bytes(int64_t n);
+int row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int kind, float scale, float* out,
+                 void* ws, size_t ws_bytes, hipStream_t s);
+int row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
+                 float scale, float* ga, hipStream_t s);
 size_t update_position_ws_bytes(int64_t V, int64_t F);
 int update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval, const float* normals,
                      const float* dd, int64_t V, int64_t F, int n_iter, float* out, void* ws, size_t ws_bytes,

@@ -167,6 +167,60 @@ __global__ void head_dh_kernel(const float* __restrict__ graw, int nout, const f
   *reinterpret_cast<float4*>(dh + t) = s;
 }
 
+// ------------------------------------------------------------------- losses and metrics
+// network.py:364-413.  One pass per call: per-row term, optional per-row weight (per-mesh means of a
+// disjoint-union batch), block partials, fixed-order final sum (deterministic, no atomics).
+//   kind 0: L1  sum_c |a - b|      kind 1: L2  sum_c (a - b)^2         (loss_v / loss_n)
+//   kind 2: Euclidean distance     kind 3: angle in degrees, acos(clamp(1 - |a - b|^2 / 2))   (error_v / error_n)
+__device__ __forceinline__ float row_term(const float* __restrict__ a, const float* __restrict__ b, int kind) {
+  float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+  if (kind == 0) return fabsf(d0) + fabsf(d1) + fabsf(d2);
+  float sq = d0 * d0 + d1 * d1 + d2 * d2;
+  if (kind == 1) return sq;
+  if (kind == 2) return sqrtf(sq);
+  float v = fminf(fmaxf(1.0f - sq * 0.5f, -1.0f), 1.0f);
+  return acosf(v) * 57.29577951308232f;
+}
+
+__global__ __launch_bounds__(256) void row_loss_partial_kernel(const float* __restrict__ a,
+                                                               const float* __restrict__ b,
+                                                               const float* __restrict__ w, int64_t n, int kind,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float t = row_term(a + 3 * i, b + 3 * i, kind);
+    s += w ? t * w[i] : t;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void row_loss_final_kernel(const float* __restrict__ partial, int blocks, float scale,
+                                      float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[b];
+  out[0] = s * scale;
+}
+
+// d loss / d a  for kinds 0 and 1:  g[i, c] = gout * scale * w_i * (sign(d) | 2 d)
+__global__ void row_loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                    const float* __restrict__ w, const float* __restrict__ gout, float scale,
+                                    int64_t n, int kind, float* __restrict__ ga) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * n) return;
+  float d = a[t] - b[t];
+  float g = gout[0] * scale * (w ? w[t / 3] : 1.0f);
+  // torch: d|x|/dx = sign(x) with sign(0) = 0
+  ga[t] = kind == 0 ? g * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f)) : g * 2.0f * d;
+}
+
 // ---------------------------------------------------------------- vertex update (f1)
 __global__ void centroid_kernel(const float* __restrict__ pts, const int* __restrict__ fv, int F,
                                 float* __restrict__ cent) {
@@ -204,6 +258,34 @@ __global__ void vertex_update_kernel(const float* __restrict__ pts, const float*
 }
 
 }  // namespace
+
+static int loss_blocks(int64_t n) {
+  int64_t b = (n + 1023) / 1024;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+size_t row_loss_ws_bytes(int64_t n) { return align_up((size_t)loss_blocks(n) * sizeof(float)) + 256; }
+
+int row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int kind, float scale, float* out,
+                 void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(n > 0 && kind >= 0 && kind <= 3, "row_loss: bad arguments");
+  Arena ar(ws, ws_bytes);
+  int blocks = loss_blocks(n);
+  float* partial = ar.take<float>(blocks);
+  GEOBI_REQUIRE(ar.ok() && partial, "row_loss: workspace too small");
+  row_loss_partial_kernel<<<blocks, 256, 0, s>>>(a, b, w, n, kind, partial);
+  row_loss_final_kernel<<<1, 64, 0, s>>>(partial, blocks, scale, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
+                 float scale, float* ga, hipStream_t s) {
+  GEOBI_REQUIRE(n > 0 && (kind == 0 || kind == 1), "row_loss_bwd: only L1 / L2 are differentiable here");
+  row_loss_bwd_kernel<<<cdiv(3 * n, 256), 256, 0, s>>>(a, b, w, gout, scale, n, kind, ga);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
 
 size_t update_position_ws_bytes(int64_t V, int64_t F) {
   return align_up((size_t)F * 3 * sizeof(float)) + align_up((size_t)V * 3 * sizeof(float)) + 512;

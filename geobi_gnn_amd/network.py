@@ -105,22 +105,23 @@ class DualGNN(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------
+_KIND = {'L1': 0, 'L2': 1}
+
+
 def loss_v(vp, v, dis='L2', apply_icp=False):
+    """network.py:364-377: mean over vertices of sum_c |d| ('L1') or sum_c d^2 ('L2')."""
     if apply_icp:
         raise NotImplementedError('ICP alignment needs pytorch3d, which the reference treats as optional')
-    if dis == 'L1':
-        return (vp - v).abs().sum(1).mean()
-    if dis == 'L2':
-        return (vp - v).pow(2).sum(1).mean()
-    raise NotImplementedError("loss_v: %r relies on kaolin, which the reference never imports" % (dis,))
+    if dis not in _KIND:
+        raise NotImplementedError("loss_v: %r relies on kaolin, which the reference never imports" % (dis,))
+    return ops.row_loss(vp, v, _KIND[dis])
 
 
 def loss_n(np, n, norm='L1', fc_p=None, fc=None):
-    if norm == 'L1':
-        return (np - n).abs().sum(1).mean()
-    if norm == 'L2':
-        return (np - n).pow(2).sum(1).mean()
-    raise NotImplementedError("loss_n: %r relies on kaolin, which the reference never imports" % (norm,))
+    """network.py:380-389."""
+    if norm not in _KIND:
+        raise NotImplementedError("loss_n: %r relies on kaolin, which the reference never imports" % (norm,))
+    return ops.row_loss(np, n, _KIND[norm])
 
 
 def dual_loss(loss_v, loss_n, v_scale=1, n_scale=1, alpha=None):
@@ -130,15 +131,13 @@ def dual_loss(loss_v, loss_n, v_scale=1, n_scale=1, alpha=None):
 
 
 def error_v(vp, v):
-    """Mean Euclidean distance."""
-    return (vp - v).pow(2).sum(1).pow(0.5).mean()
+    """Mean Euclidean distance (network.py:399-404)."""
+    return ops.row_loss(vp.detach(), v, 2)
 
 
 def error_n(np, n):
-    """Mean angle (degrees) between unit normals."""
-    error = (np - n).pow(2).sum(1)
-    val = torch.clamp(1 - error / 2, min=-1, max=1)
-    return (torch.acos(val) * 180 / math.pi).mean()
+    """Mean angle in degrees between unit normals (network.py:407-413)."""
+    return ops.row_loss(np.detach(), n, 3)
 
 
 def laplacian_loss(vp, v, edge_idx_v, normal=None):

@@ -295,3 +295,40 @@ class HeadFn(Function):
                L.ptr(dd), L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2),
                L.ptr(db2), L.ptr(ws), ws.numel(), L.stream())
         return (dx,) + ret + (None, None, None)
+
+
+# ------------------------------------------------------------------------ losses / metrics
+class RowLossFn(Function):
+    """scale * sum_i w_i * term(a_i, b_i) over [n, 3] rows (network.py:364-413; kinds in geobi_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, a, b, w, kind, scale):
+        L.require_device(a, 'prediction')
+        a, b = _f32c(a), _f32c(b.detach())
+        if a.dim() != 2 or a.shape[1] != 3 or b.shape != a.shape:
+            raise L.GeobiError('row loss expects two [n, 3] tensors, got %s and %s' % (tuple(a.shape), tuple(b.shape)))
+        w = None if w is None else _f32c(w)
+        n = a.shape[0]
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        ws = L.workspace(L.lib().geobi_row_loss_ws_bytes(n), a.device)
+        L.call('geobi_row_loss_fwd', L.ptr(a), L.ptr(b), L.ptr(w), n, int(kind), float(scale), L.ptr(out), L.ptr(ws),
+               ws.numel(), L.stream())
+        ctx.kind, ctx.scale, ctx.has_w = int(kind), float(scale), w is not None
+        ctx.save_for_backward(a, b, w if w is not None else a)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b, w = ctx.saved_tensors
+        if ctx.kind > 1:
+            raise L.GeobiError('error_v / error_n are metrics: no gradient is defined (the reference never needs one)')
+        ga = torch.empty_like(a)
+        g = gout.reshape(1).float().contiguous()
+        L.call('geobi_row_loss_bwd', L.ptr(a), L.ptr(b), L.ptr(w) if ctx.has_w else None, L.ptr(g), a.shape[0],
+               ctx.kind, ctx.scale, L.ptr(ga), L.stream())
+        return ga, None, None, None, None
+
+
+def row_loss(a, b, kind, weights=None, scale=None):
+    n = a.shape[0]
+    return RowLossFn.apply(a, b, weights, kind, (1.0 / n) if scale is None else scale)

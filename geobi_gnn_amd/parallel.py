@@ -111,11 +111,33 @@ def reduce_sums(values, device):
     return t.double().tolist()
 
 
+def _mesh_weights(data):
+    """Per-row weights 1 / (B * n_mesh) of a disjoint-union batch (cached on the Data bag)."""
+    ptr = getattr(data, 'mesh_ptr', None)
+    if ptr is None or ptr.numel() <= 2:
+        return None
+    w = getattr(data, '_loss_weights', None)
+    if w is None or w.device != data.y.device:
+        counts = ptr[1:] - ptr[:-1]
+        w = torch.repeat_interleave(1.0 / (counts.float() * counts.numel()), counts).to(data.y.device)
+        data._loss_weights = w
+    return w
+
+
 def batched_losses(vp, npred, data_v, data_f, loss_v='L1', loss_n='L1'):
     """Per-mesh mean losses averaged over the meshes of a disjoint-union batch.
 
     Identical to accumulating ``loss / batch_size`` over sequential single-mesh steps
-    (train_dual.py:204-212).  Without ``mesh_ptr`` it is the plain per-node mean."""
+    (train_dual.py:204-212).  Without ``mesh_ptr`` it is the plain per-node mean.  On the MI355X
+    this is the fused reduction kernel (geobi_row_loss_*); CPU tensors (gloo tests) use torch ops."""
+    kinds = {'L1': 0, 'L2': 1}
+    if vp.is_cuda:
+        from . import ops
+        wv, wn = _mesh_weights(data_v), _mesh_weights(data_f)
+        lv = ops.row_loss(vp, data_v.y, kinds[loss_v], wv, 1.0 if wv is not None else None)
+        ln = ops.row_loss(npred, data_f.y, kinds[loss_n], wn, 1.0 if wn is not None else None)
+        return lv, ln
+
     def per_node(a, b, kind):
         d = a - b
         return d.abs().sum(1) if kind == 'L1' else d.pow(2).sum(1)

@@ -167,6 +167,18 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const fl
                    float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* ---------------------------------------------------------------- losses / metrics ---------
+ * code/network.py:364-413 on [n, 3] rows:  out[0] = scale * sum_i w_i * term_i  (w = NULL: w_i = 1)
+ *   kind 0  L1   sum_c |a - b|          (loss_v / loss_n 'L1')       kind 1  L2  sum_c (a - b)^2
+ *   kind 2  Euclidean distance          (error_v)                    kind 3  angle in degrees (error_n)
+ * scale = 1/n gives the reference's `.mean()`; per-row weights give per-mesh means of a batch.
+ * Deterministic two-stage reduction.  _bwd (kinds 0, 1): ga = gout[0] * scale * w_i * d term / d a.  */
+size_t geobi_row_loss_ws_bytes(int64_t n);
+int geobi_row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int kind, float scale, float* out,
+                       void* ws, size_t ws_bytes, void* stream);
+int geobi_row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
+                       float scale, float* ga, void* stream);
+
 /* ---------------------------------------------------------------- vertex update ----
  * data_util.update_position2 (code/data_util.py:529-556; called at code/test_dual.py:63-72 after the
  * network): n_iter Jacobi sweeps  p_v += mean_{f adj v} n_f (n_f . (c_f - p_v)), c_f = face centroid,

@@ -286,7 +286,7 @@ def test_angular_error_statistical_parity(dev):
                        fv_indices=df.fv_indices.clone())
             _, no, _ = ora((a, b))
         F_ = df.y.shape[0]
-        tot_h += network.error_n(nh.cpu(), df.y).item() * F_
+        tot_h += network.error_n(nh, df.y.to(dev)).item() * F_
         tot_o += R.error_n(no, df.y).item() * F_
         cnt += F_
     err_h, err_o = tot_h / cnt, tot_o / cnt
@@ -317,3 +317,36 @@ def test_direct_gradient_writes_match_autograd_accumulation(dev):
     assert torch.equal(flat.bucket.flat, g_direct)          # the bucket IS the gradient storage
     flat.bucket.zero()
     assert torch.equal(grads(), g_ref)                        # and stays valid step after step
+
+
+def test_losses_and_metrics_match_reference_fixture(dev):
+    """network.loss_v / loss_n / error_v / error_n (fused reduction kernels) vs the values the reference's
+    own functions produced (tests/golden/pure_functions.npz) and vs autograd of the oracle."""
+    from geobi_gnn_amd import network
+    from geobi_gnn_amd.parallel import batched_losses
+    from geobi_gnn_amd.data import Data
+    from oracle import ref_model as R
+    fx = load_fixture('pure_functions.npz')
+    a, b = torch.from_numpy(fx['a']).to(dev), torch.from_numpy(fx['b']).to(dev)
+    an, bn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(b, dim=1)
+    close = lambda x, ref: abs(float(x) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-7
+    assert close(network.loss_v(a, b, 'L1'), fx['loss_v_L1']) and close(network.loss_v(a, b, 'L2'), fx['loss_v_L2'])
+    assert close(network.loss_n(an, bn, 'L1'), fx['loss_n_L1']) and close(network.loss_n(an, bn, 'L2'), fx['loss_n_L2'])
+    assert close(network.error_v(a, b), fx['error_v'])
+    assert abs(float(network.error_n(an, bn)) - float(fx['error_n'])) < 1e-3
+    assert close(network.dual_loss(network.loss_v(a, b, 'L1'), network.loss_n(an, bn, 'L1'), 2.0, 0.5),
+                 2.0 * float(fx['loss_v_L1']) + 0.5 * float(fx['loss_n_L1']))
+    # gradients vs the oracle's autograd
+    for kind in ('L1', 'L2'):
+        ah = a.clone().requires_grad_(True)
+        (network.loss_v(ah, b, kind) * 3.0).backward()
+        ao = a.cpu().clone().requires_grad_(True)
+        (R.loss_v(ao, b.cpu(), kind) * 3.0).backward()
+        assert rel_err(ah.grad.cpu(), ao.grad) < 1e-6
+    # per-mesh means of a union batch
+    dv = Data(None, None, y=b); dv.mesh_ptr = torch.tensor([0, 20, 50])
+    df = Data(None, None, y=bn); df.mesh_ptr = torch.tensor([0, 10, 50])
+    lv, ln = batched_losses(a, an, dv, df)
+    want_v = 0.5 * ((a[:20] - b[:20]).abs().sum(1).mean() + (a[20:] - b[20:]).abs().sum(1).mean())
+    want_n = 0.5 * ((an[:10] - bn[:10]).abs().sum(1).mean() + (an[10:] - bn[10:]).abs().sum(1).mean())
+    assert close(lv, want_v) and close(ln, want_n)
