@@ -350,3 +350,105 @@ def test_losses_and_metrics_match_reference_fixture(dev):
     want_v = 0.5 * ((a[:20] - b[:20]).abs().sum(1).mean() + (a[20:] - b[20:]).abs().sum(1).mean())
     want_n = 0.5 * ((an[:10] - bn[:10]).abs().sum(1).mean() + (an[10:] - bn[10:]).abs().sum(1).mean())
     assert close(lv, want_v) and close(ln, want_n)
+
+
+def _edge_map(ei, w, n):
+    key = (ei[0] * n + ei[1]).cpu()
+    order = torch.argsort(key)
+    return key[order], w.detach().cpu()[order]
+
+
+@pytest.mark.parametrize('wtype', [-1, 0, 1, 2, 6, 7, 8, 9, 10])
+def test_edge_weight_types_match_oracle(dev, wtype):
+    """PoolingLayer._get_edge_weight, every non-learned edge_weight_type (net_util.py:169-230)."""
+    from geobi_gnn_amd import net_util, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    dv, _ = meshgen.synthetic_dual_data(5, 0.2, seed=wtype + 20)
+    torch.manual_seed(wtype + 5)
+    feat = torch.randn(dv.x.shape[0], 32) * 0.3
+    n = feat.shape[0]
+    ora = R.PoolingLayer(32, 'max', 2, wtype, wei_param=3)
+    do = P.Data(feat.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone())
+    w_o = ora._get_edge_weight(do)
+    hip = net_util.PoolingLayer(32, 'max', 2, wtype, wei_param=3).to(dev)
+    dh = dv.to(dev)
+    dh.x = feat.to(dev)
+    w_h = hip._get_edge_weight(dh)
+    # both rewrote their input loop-free; orders differ (input order vs (row, col)-sorted)
+    ko, _ = _edge_map(do.edge_index, do.edge_weight, n)
+    kh, _ = _edge_map(dh.edge_index, dh.edge_weight, n)
+    assert torch.equal(ko, kh)
+    assert rel_err(_edge_map(dh.edge_index, dh.edge_weight, n)[1], _edge_map(do.edge_index, do.edge_weight, n)[1].double()) < 1e-6
+    if wtype == -1:
+        assert w_o is None and w_h is None
+    else:
+        assert rel_err(_edge_map(dh.edge_index, w_h, n)[1], _edge_map(do.edge_index, w_o, n)[1].double()) < 2e-5
+
+
+def test_mean_pooling_model_against_oracle(dev):
+    """pool_type='mean' (the reference's other branch, net_util.py:131-132) through the whole network."""
+    from geobi_gnn_amd import network, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(R.DualGNN(pool_type='mean').state_dict(), 8)
+    net = network.DualGNN(pool_type='mean').to(dev)
+    net.load_state_dict(sd)
+    dv, df = meshgen.synthetic_dual_data(6, 0.2, seed=4)
+    dvo = P.Data(dv.x.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone(), y=dv.y.clone())
+    dfo = P.Data(df.x.clone(), df.edge_index.clone(), edge_weight=df.edge_weight.clone(), y=df.y.clone(),
+                 fv_indices=df.fv_indices.clone())
+    vp, npred, loss, _ = _step(net, network, dv.to(dev), df.to(dev))
+    raw = []
+    for m in (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2):
+        raw += [c.cpu() for c in m.last_clusters]
+    ora = R.DualGNN(pool_type='mean')
+    ora.load_state_dict(sd)
+    install_replay(ora, raw)
+    vo, no, loss_o, _ = _step(ora, R, dvo, dfo)
+    assert rel_err(vp.cpu(), vo) < OUT_TOL and rel_err(npred.cpu(), no) < OUT_TOL
+    assert abs(loss - loss_o) < 1e-5 * abs(loss_o)
+    for (k, ph), (_, po) in zip(net.named_parameters(), ora.named_parameters()):
+        assert rel_err(ph.grad.cpu(), po.grad) < _grad_tol(k), k
+
+
+def test_degenerate_graphs(dev):
+    """Tiny and edge-free graphs: one node, one edge, a pooling step that removes every edge
+    (the `edge_index.numel() == 0` break of net_util.py:139), isolated nodes."""
+    from geobi_gnn_amd import net_util
+    from geobi_gnn_amd.data import Data
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    from oracle import ref_model as R, pyg_ops as P
+    torch.manual_seed(0)
+    cases = {
+        'single node, no edges': (1, torch.zeros((2, 0), dtype=torch.long)),
+        'self loop only': (1, torch.tensor([[0], [0]])),
+        'one edge': (2, torch.tensor([[0, 1], [1, 0]])),
+        'path of 3 + isolated': (4, torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])),
+        'star': (6, torch.tensor([[0, 1, 0, 2, 0, 3, 0, 4, 0, 5], [1, 0, 2, 0, 3, 0, 4, 0, 5, 0]])),
+    }
+    for name, (n, ei) in cases.items():
+        x = torch.randn(n, 32)
+        w = torch.rand(ei.shape[1])
+        conv_o = P.FeaStConv(32, 64, 9)
+        conv_h = FeaStConv(32, 64, 9).to(dev)
+        conv_h.load_state_dict(conv_o.state_dict())
+        xo = x.clone().requires_grad_(True)
+        out_o = conv_o(xo, ei)
+        out_o.sum().backward()
+        xh = x.to(dev).requires_grad_(True)
+        out_h = conv_h(xh, ei.to(dev))
+        out_h.sum().backward()
+        assert rel_err(out_h.detach().cpu(), out_o.detach()) < OUT_TOL, name
+        assert rel_err(xh.grad.cpu(), xo.grad) < 1e-4, name
+        # pooling: HIP matching replayed on the oracle
+        layer_h = net_util.PoolingLayer(32, 'max', 2, 10).to(dev)
+        out = layer_h(Data(x.to(dev), ei.to(dev), edge_weight=w.to(dev)))
+        layer_o = R.PoolingLayer(32, 'max', 2, 10)
+        clusters = iter([c.cpu() for c in layer_h.last_clusters])
+        layer_o.graclus_fn = lambda e, ww=None, nn=None: next(clusters)
+        ref = layer_o(P.Data(x.clone(), ei.clone(), edge_weight=w.clone()))
+        assert torch.equal(out.x.cpu(), ref.x), name
+        assert torch.equal(layer_h.unpooling_indices.cpu(), layer_o.unpooling_indices), name
+        eh = out.edge_index.cpu() if out.edge_index is not None else torch.zeros((2, 0), dtype=torch.long)
+        assert eh.shape[1] == ref.edge_index.shape[1], name
+        assert torch.equal(layer_h.unpooling(out.x).cpu(), layer_o.unpooling(ref.x)), name
