@@ -1,0 +1,123 @@
+"""Training driver counterpart of /root/reference/code/train_dual.py:100-281 on synthetic meshes.
+
+Same loop structure and flag names for the parts that touch the hot path -- gradient accumulation
+over ``--batch_size`` meshes (here: one disjoint-union step), L1/L2 losses with scales, Adam / SGD /
+RMSprop, step / exp / lambda LR schedules, per-epoch evaluation with node-count-weighted means
+(train_dual.py:233-263), best-on-eval checkpoint with the reference's state-dict keys.  The datasets
+of the reference are external downloads, so meshes are noisy icospheres (meshgen.py).  Data parallel:
+launch through ``python -m torch.distributed.run --nproc-per-node N tools/train_synthetic.py ...``;
+meshes are sharded by rank and the flat gradient bucket is all-reduced once per step.
+
+  python tools/train_synthetic.py --max_epoch 5 --batch_size 4 --freq 16 --n_train 12 --n_eval 4
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geobi_gnn_amd import network, meshgen          # noqa: E402
+from geobi_gnn_amd.data import union_batch           # noqa: E402
+from geobi_gnn_amd.parallel import (init_distributed, FlatParameters, shard_indices, batched_losses,   # noqa: E402
+                                    reduce_sums)
+
+
+def parse_arguments():
+    p = argparse.ArgumentParser()
+    p.add_argument('--freq', type=int, default=16, help='icosphere frequency (F = 20 freq^2)')
+    p.add_argument('--n_train', type=int, default=12)
+    p.add_argument('--n_eval', type=int, default=4)
+    p.add_argument('--loss_v', type=str, default='L1')
+    p.add_argument('--loss_n', type=str, default='L1')
+    p.add_argument('--loss_v_scale', type=float, default=1)
+    p.add_argument('--loss_n_scale', type=float, default=1)
+    p.add_argument('--wei_param', type=int, default=2)
+    p.add_argument('--max_epoch', type=int, default=10)
+    p.add_argument('--batch_size', type=int, default=4)
+    p.add_argument('--lr', type=float, default=1e-3)
+    p.add_argument('--lr_sch', type=str, default='lmd', choices=['lmd', 'step', 'exp', 'none'])
+    p.add_argument('--lr_step', type=int, default=50)
+    p.add_argument('--lr_decay', type=float, default=0.5)
+    p.add_argument('--optimizer', type=str, default='adam', choices=['adam', 'sgd', 'rmsprop'])
+    p.add_argument('--seed', type=int, default=40938661)
+    p.add_argument('--out', type=str, default='')
+    return p.parse_args()
+
+
+def main():
+    opt = parse_arguments()
+    rank, world, device = init_distributed()
+    assert torch.cuda.is_available(), 'the geobi path runs on the MI355X only'
+    torch.manual_seed(opt.seed)
+    sigmas = (0.1, 0.2, 0.3)
+    train = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=1000 + i) for i in range(opt.n_train)]
+    evals = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=5000 + i) for i in range(opt.n_eval)]
+    evals = [(a.to(device), b.to(device)) for a, b in evals]
+
+    net = network.DualGNN(force_depth=False, pool_type='max', wei_param=opt.wei_param).to(device)
+    flat = FlatParameters(net)
+    params = flat.parameters()
+    if opt.optimizer == 'adam':
+        optimizer = torch.optim.Adam(params, lr=opt.lr)
+    elif opt.optimizer == 'sgd':
+        optimizer = torch.optim.SGD(params, lr=opt.lr, momentum=0.9)
+    else:
+        optimizer = torch.optim.RMSprop(params, lr=opt.lr)
+    if opt.lr_sch == 'step':
+        sch = torch.optim.lr_scheduler.StepLR(optimizer, opt.lr_step, opt.lr_decay)
+    elif opt.lr_sch == 'exp':
+        sch = torch.optim.lr_scheduler.ExponentialLR(optimizer, 0.99)
+    elif opt.lr_sch == 'lmd':
+        sch = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: max(0.0, 1 - e / float(opt.max_epoch)) * 0.9 + 0.1)
+    else:
+        sch = None
+
+    best, history = math.inf, []
+    for epoch in range(1, opt.max_epoch + 1):
+        net.train()
+        mine = shard_indices(len(train), rank, world, seed=opt.seed, epoch=epoch)
+        t0 = time.time()
+        for s in range(0, len(mine), opt.batch_size):
+            dv, df = union_batch([train[i] for i in mine[s:s + opt.batch_size]])
+            dv, df = dv.to(device), df.to(device)
+            flat.bucket.zero()
+            vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+            lv, ln = batched_losses(vp, npred, dv, df, opt.loss_v, opt.loss_n)
+            loss = network.dual_loss(lv, ln, opt.loss_v_scale, opt.loss_n_scale)
+            loss.backward()
+            flat.bucket.all_reduce_mean()
+            optimizer.step()
+        # evaluation: node-count-weighted means over the eval meshes of every rank
+        net.eval()
+        sums = [0.0] * 6
+        with torch.no_grad():
+            for a, b in evals[rank::world]:
+                vp, npred, _ = net((a.shallow_copy(), b.shallow_copy()))
+                nv, nf = a.y.shape[0], b.y.shape[0]
+                sums[0] += float(network.loss_v(vp, a.y, opt.loss_v)) * nv
+                sums[1] += float(network.loss_n(npred, b.y, opt.loss_n)) * nf
+                sums[2] += float(network.error_v(vp, a.y)) * nv
+                sums[3] += float(network.error_n(npred, b.y)) * nf
+                sums[4] += nv
+                sums[5] += nf
+        sums = reduce_sums(sums, device)
+        rec = {'epoch': epoch, 'train_loss': float(loss.detach()), 'eval_loss_v': sums[0] / sums[4], 'eval_loss_f': sums[1] / sums[5],
+               'eval_error_v': sums[2] / sums[4], 'eval_error_f_deg': sums[3] / sums[5],
+               'lr': optimizer.param_groups[0]['lr'], 'epoch_s': round(time.time() - t0, 3)}
+        history.append(rec)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+            if rec['eval_error_f_deg'] < best and opt.out:
+                best = rec['eval_error_f_deg']
+                torch.save(net.state_dict(), opt.out)       # keys: gnn_v.l_conv1.lin.weight ... fc_f2.bias
+        if sch is not None:
+            sch.step()
+    return history
+
+
+if __name__ == '__main__':
+    main()
