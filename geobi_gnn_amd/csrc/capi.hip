@@ -236,6 +236,16 @@ int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t*
 int geobi_gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, void* stream) {
   return gather_rows(x, idx, C, n_out, out, S(stream));
 }
+size_t geobi_pool_edge_rows_ws_bytes(int64_t nbound) { return pool_edge_rows_ws_bytes(nbound); }
+int geobi_pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
+                         const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound,
+                         int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
+                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(cnew); NOTNULL(segptr); NOTNULL(members); NOTNULL(rowptr); NOTNULL(ncount); NOTNULL(rowptr_c);
+  NOTNULL(row_c); NOTNULL(col_c); NOTNULL(count); NOTNULL(overflow);
+  return pool_edge_rows(cnew, segptr, members, rowptr, col, w, ncount, nbound, rowptr_c, row_c, col_c, w_c, count,
+                        overflow, ws, ws_bytes, S(stream));
+}
 size_t geobi_pool_edge_ws_bytes(int64_t E) { return pool_edge_ws_bytes(E); }
 int geobi_pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E,
                     int64_t nmax, int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,

@@ -314,6 +314,81 @@ __global__ void pool_edge_emit_kernel(const uint64_t* __restrict__ keys, const i
   }
 }
 
+// ---------------------------------------------------------- pool_edge, sort-free (matchings)
+// For a matching every coarse node has 1-2 members, so its coarse row is the union of at most two
+// fine rows: one wave per coarse node gathers those (<= 64) entries, relabels them, sorts them with a
+// 64-lane bitonic network, drops the self entry and merges duplicates -- no global radix sort.
+// PASS 0 counts the unique neighbours (-> exclusive scan -> rowptr), PASS 1 repeats and writes.
+// Rows with more than 64 gathered entries set `overflow` (the caller falls back to the sorted path).
+template <int PASS>
+__global__ __launch_bounds__(256) void pool_edge_rows_kernel(
+    const int* __restrict__ cnew, const int* __restrict__ segptr, const int* __restrict__ members,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ w,
+    const int* __restrict__ ncount, int nbound, int* __restrict__ cnt, const int* __restrict__ rowptr_c,
+    int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (A >= nbound) return;
+  const int nc = *ncount;
+  if (A >= nc) { if (PASS == 0) cnt[A] = 0; return; }
+  const int ms = segptr[A], me = segptr[A + 1];
+  const int m0 = members[ms];
+  const int m1 = (me - ms > 1) ? members[ms + 1] : -1;
+  const int r0 = rowptr[m0], d0 = rowptr[m0 + 1] - r0;
+  const int r1 = m1 >= 0 ? rowptr[m1] : 0, d1 = m1 >= 0 ? rowptr[m1 + 1] - r1 : 0;
+  if (PASS == 0 && lane == 0 && (d0 + d1 > 64 || me - ms > 2)) atomicOr(overflow, 1);
+  int key = 0x7fffffff;
+  float val = 0.f;
+  if (lane < d0 + d1) {
+    const int e = lane < d0 ? r0 + lane : r1 + (lane - d0);
+    int k = cnew[col[e]];
+    if (k != A) { key = k; val = w ? w[e] : 0.f; }
+  }
+  // bitonic sort, ascending by key
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int pk = __shfl_xor(key, j, 64);
+      const float pv = __shfl_xor(val, j, 64);
+      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+      const bool take = keep_min ? (pk < key) : (pk > key);
+      if (take) { key = pk; val = pv; }
+    }
+  }
+  const int prev = __shfl_up(key, 1, 64);
+  const bool head = key != 0x7fffffff && (lane == 0 || prev != key);
+  const unsigned long long hm = __ballot(head);
+  if (PASS == 0) {
+    if (lane == 0) cnt[A] = __popcll(hm);
+    return;
+  }
+  // run of duplicates starting at a head lane: up to the next head (or the first invalid lane)
+  const unsigned long long vm = __ballot(key != 0x7fffffff);
+  const int nvalid = __popcll(vm);
+  const unsigned long long after = (lane >= 63) ? 0ull : (hm >> (lane + 1));
+  const int next = after ? lane + 1 + (__ffsll((long long)after) - 1) : nvalid;
+  const int len = head ? next - lane : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m, 64));
+  double sum = (double)val;
+  for (int t = 1; t < maxlen; ++t) {
+    float v = __shfl_down(val, t, 64);
+    if (t < len) sum += (double)v;
+  }
+  if (head) {
+    const int pos = rowptr_c[A] + __popcll(hm & ((1ull << lane) - 1ull));
+    row_c[pos] = A;
+    col_c[pos] = key;
+    if (w) w_c[pos] = (float)(sum / (double)len);
+  }
+}
+
+__global__ void pool_rows_total_kernel(const int* __restrict__ rowptr_c, int nbound, int* __restrict__ count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = rowptr_c[nbound];
+}
+
 __global__ void pool_edge_rowptr_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ count, int nmax,
                                         int bits, int* __restrict__ rowptr) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,6 +618,36 @@ int segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segpt
 int gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, hipStream_t s) {
   if (n_out <= 0) return 0;
   gather_rows_kernel<<<cdiv(n_out * C, 256), 256, 0, s>>>(x, idx, C, n_out * C, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t pool_edge_rows_ws_bytes(int64_t nbound) {
+  return align_up((size_t)(nbound + 1) * sizeof(int)) + align_up(scan_temp_bytes<int>(nbound + 1)) + 512;
+}
+
+// cnew, (segptr, members) = pair lists built with the bound `nbound` (fine node count), ncount = device
+// count of coarse nodes.  rowptr_c has nbound + 1 entries; count[0] = coarse edges; overflow[0] |= 1 if
+// some row did not fit (outputs are then incomplete and the caller must use pool_edge).
+int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
+                   const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
+                   int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
+                   size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(nbound > 0, "pool_edge_rows: empty");
+  Arena a(ws, ws_bytes);
+  int* cnt = a.take<int>(nbound + 1);
+  size_t tb = scan_temp_bytes<int>(nbound + 1);
+  void* temp = a.take<char>(tb ? tb : 1);
+  GEOBI_REQUIRE(a.ok() && cnt, "pool_edge_rows: workspace too small");
+  GEOBI_HIP(hipMemsetAsync(cnt + nbound, 0, sizeof(int), s));
+  int blocks = cdiv(nbound, 4);
+  pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
+                                                   nullptr, nullptr, nullptr, nullptr, overflow);
+  GEOBI_LAUNCH_OK();
+  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, rowptr_c, 0, (size_t)(nbound + 1), rocprim::plus<int>(), s, false));
+  pool_edge_rows_kernel<1><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
+                                                   rowptr_c, row_c, col_c, w_c, overflow);
+  pool_rows_total_kernel<<<1, 64, 0, s>>>(rowptr_c, (int)nbound, count);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -78,33 +78,58 @@ def _pool_edge_raw(cnew32, graph, weight_sorted, count=None):
     return rowptr_c, row_c, col_c, w_c, count
 
 
+def _pool_edge_rows(cnew32, sidx, graph, weight_sorted, ncount, count, overflow):
+    """Sort-free pool_edge for a matching (geobi_pool_edge_rows); worst-case sized outputs."""
+    dev = graph.device
+    cap = max(graph.E, 1)
+    rowptr_c = torch.empty(graph.N + 1, dtype=torch.int32, device=dev)
+    row_c = torch.empty(cap, dtype=torch.int32, device=dev)
+    col_c = torch.empty(cap, dtype=torch.int32, device=dev)
+    w_c = None if weight_sorted is None else torch.empty(cap, dtype=torch.float32, device=dev)
+    ws = L.workspace(L.lib().geobi_pool_edge_rows_ws_bytes(graph.N), dev)
+    L.call('geobi_pool_edge_rows', L.ptr(cnew32), L.ptr(sidx.segptr), L.ptr(sidx.members), L.ptr(graph.rowptr_out),
+           L.ptr(graph.col_out), L.ptr(None if weight_sorted is None else weight_sorted.contiguous()), L.ptr(ncount),
+           graph.N, L.ptr(rowptr_c), L.ptr(row_c), L.ptr(col_c), L.ptr(w_c), L.ptr(count), L.ptr(overflow),
+           L.ptr(ws), ws.numel(), L.stream())
+    return rowptr_c, row_c, col_c, w_c
+
+
 def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
     """One pooling step on the structure: match (unless given) -> relabel -> pool_edge.
 
-    One host sync reads {undecided nodes, coarse node count, coarse edge count}.
-    Returns (cnew int32, coarse Graph, coarse weights, raw cluster int32)."""
+    One host sync reads {undecided nodes, coarse node count, coarse edge count, overflow}.
+    Returns (cnew int32, coarse Graph, coarse weights, raw cluster int32, inverse lists or None)."""
+    sidx = None
     if cluster32 is None:
         state, total = None, 0
         while True:
-            # one int32[4] holds {undecided, N', E'}: one fill, one device-to-host read per step
+            # one int32[4] holds {undecided, N', E', overflow}: one fill, one device-to-host read per step
             counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
             cluster32, _, state = hip_match(graph, weight_sorted, rounds, state, status=counters[0:1])
             total += rounds
             cnew, _ = relabel(cluster32, count=counters[1:2])
-            rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
-            undecided, nc, ec, _ = counters.tolist()
+            # inverse lists of the matching, sized by the fine node count (N' is still on the device)
+            sidx = ops.SegmentIndex.from_matching(cnew, cluster32, graph.N)
+            rowptr_c, row_c, col_c, w_c = _pool_edge_rows(cnew, sidx, graph, weight_sorted, counters[1:2],
+                                                          counters[2:3], counters[3:4])
+            undecided, nc, ec, overflow = counters.tolist()
+            if overflow:     # a coarse node gathers > 64 fine entries: take the radix-sort path
+                count = torch.zeros(1, dtype=torch.int32, device=graph.device)
+                rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=count)
+                ec = int(count.item())
             # rare: proposal chains longer than the rounds run so far -> resume from the saved state.
             # Beyond MATCH_ROUNDS_MAX the undecided nodes stay singletons (still a valid clustering).
             if not undecided or total >= MATCH_ROUNDS_MAX:
                 break
             rounds = min(rounds * 2, MATCH_ROUNDS_MAX - total)
+        sidx.narrow(nc)
     else:
         counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
         cnew, _ = relabel(cluster32, count=counters[1:2])
         rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
         _, nc, ec, _ = counters.tolist()
     coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec], symmetric=graph.symmetric)
-    return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32
+    return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32, sidx
 
 
 def _pool_features(x, sidx, pool_type):
@@ -211,10 +236,11 @@ class PoolingLayer(nn.Module):
             given = None
             if self.graclus_fn is not None:
                 given = _i32(self.graclus_fn(g.coo64(), edge_weight, g.N))
-            cnew, g_c, w_c, cl_raw = _coarsen(g, edge_weight, given)
+            cnew, g_c, w_c, cl_raw, sidx = _coarsen(g, edge_weight, given)
             raw.append(cl_raw)
             clusts.append(cnew)
-            sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
+            if sidx is None:
+                sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
             sidxs.append(sidx)
             x = _pool_features(x, sidx, self.pool_type)
             pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
@@ -273,9 +299,8 @@ def pooling(data, p_type='max', level=2, wei_type=0):
         w = _feature_gauss(x, g, 2)
     clusts = []
     for _ in range(level):
-        cnew, g_c, w_c, _ = _coarsen(g, w)
+        cnew, g_c, w_c, _, sidx = _coarsen(g, w)
         clusts.append(cnew)
-        sidx = ops.SegmentIndex(cnew, g_c.N)
         x = _pool_features(x, sidx, p_type)
         pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
         g, w = g_c, w_c
@@ -293,7 +318,7 @@ def pooling_pre(data, step=2, level=2):
     for i in range(1, level + 1):
         clusters = []
         for _ in range(step):
-            cnew, g, w, _ = _coarsen(g, w)
+            cnew, g, w, _, _ = _coarsen(g, w)
             clusters.append(cnew.long())
         setattr(data, 'pool_l%d' % i, {'clusters': clusters, 'cluster_inv': _compose(clusters).long()})
     data.edge_weight = None

@@ -126,6 +126,12 @@ class SegmentIndex(object):
                L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
         return self
 
+    def narrow(self, nseg):
+        """Lists built with an upper bound on the segment count: keep the first `nseg` segments."""
+        self.nseg = int(nseg)
+        self.segptr = self.segptr[:self.nseg + 1]
+        return self
+
     @staticmethod
     def compose(first, second, composed_seg32):
         """Lists of fine -> coarse for `composed_seg32 = second.seg[first.seg]`."""

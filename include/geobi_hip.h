@@ -137,6 +137,15 @@ int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_
 int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine,
                            float* gx, void* stream);
 int geobi_gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, void* stream);
+/* Sort-free pool_edge for a MATCHING: one wave per coarse node merges the (at most two) fine rows of its
+ * members with a 64-lane bitonic network.  (segptr, members) = geobi_segment_csr_pairs built with
+ * nseg = nbound = fine node count; ncount = device count of coarse nodes (geobi_relabel_compact).
+ * overflow[0] |= 1 when a coarse node gathers more than 64 fine entries: use geobi_pool_edge then. */
+size_t geobi_pool_edge_rows_ws_bytes(int64_t nbound);
+int geobi_pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
+                         const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound,
+                         int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
+                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_pool_edge_ws_bytes(int64_t E);
 int geobi_pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E,
                     int64_t nmax, int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,

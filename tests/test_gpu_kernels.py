@@ -419,11 +419,11 @@ def test_sort_free_inverse_lists(dev):
     ei = _sym_graph(n, 12000, seed=31, loops=False)
     gr = Graph.from_edge_index(ei.to(dev), n)
     w = torch.rand(gr.E, generator=torch.Generator().manual_seed(1)).to(dev)
-    cnew1, g1, w1, raw1 = net_util._coarsen(gr, None)
+    cnew1, g1, w1, raw1, _ = net_util._coarsen(gr, None)
     a = ops.SegmentIndex.from_matching(cnew1, raw1, g1.N)
     b = ops.SegmentIndex(cnew1, g1.N)
     assert torch.equal(a.segptr, b.segptr) and torch.equal(a.members, b.members)
-    cnew2, g2, _, raw2 = net_util._coarsen(g1, None)
+    cnew2, g2, _, raw2, _ = net_util._coarsen(g1, None)
     a2 = ops.SegmentIndex.from_matching(cnew2, raw2, g2.N)
     comp = cnew2[cnew1.long()]
     c_fast = ops.SegmentIndex.compose(a, a2, comp)
@@ -441,3 +441,26 @@ def test_sort_free_inverse_lists(dev):
     g_fast = x.grad.clone(); x.grad = None
     ops.UnpoolFn.apply(x, c_ref).backward(gf)
     assert rel_err(g_fast.cpu(), x.grad.cpu()) < 1e-6
+
+
+def test_sort_free_pool_edge_equals_radix_path(dev):
+    """geobi_pool_edge_rows (bitonic merge per coarse node) vs geobi_pool_edge (global radix sort)."""
+    from geobi_gnn_amd import net_util
+    from geobi_gnn_amd.graph import Graph
+    for n, m, seed in ((3000, 9000, 41), (500, 400, 42), (20000, 120000, 43)):
+        ei = _sym_graph(n, m, seed=seed, loops=False)
+        gr = Graph.from_edge_index(ei.to(dev), n)
+        lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+        w = gr.weights_sorted(torch.rand(n * 37 + 11, generator=torch.Generator().manual_seed(seed))[(lo * 31 + hi) % (n * 37 + 11)].to(dev))
+        cnew, coarse, w_c, raw, sidx = net_util._coarsen(gr, w)                 # rows kernel
+        cnew2, coarse2, w_c2, _, _ = net_util._coarsen(gr, w, cluster32=raw)     # radix path on the same clusters
+        assert torch.equal(cnew, cnew2) and coarse.N == coarse2.N and coarse.E == coarse2.E
+        assert torch.equal(coarse.rowptr_out, coarse2.rowptr_out)
+        assert torch.equal(coarse.col_out, coarse2.col_out) and torch.equal(coarse.ensure_rows(), coarse2.ensure_rows())
+        assert rel_err(w_c.cpu(), w_c2.cpu().double()) < 1e-6
+    # a hub whose merged row exceeds 64 entries falls back to the radix path transparently
+    hub = torch.stack([torch.zeros(200, dtype=torch.long), torch.arange(1, 201)])
+    ei = torch.cat([hub, hub.flip(0)], 1)
+    gr = Graph.from_edge_index(ei.to(dev), 201)
+    cnew, coarse, _, raw, _ = net_util._coarsen(gr, None)
+    assert coarse.N == 200 and coarse.E == 2 * 199
