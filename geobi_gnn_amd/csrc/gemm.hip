@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
                                                       float* __restrict__ C, int ldc, int M, int N, int K,
                                                       const float* __restrict__ bias, float slope,
                                                       float* __restrict__ C1, int split, int ldc1, int k_chunk,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, int wide_store) {
   // split-K (partial != nullptr): blockIdx.z owns k in [z * k_chunk, (z+1) * k_chunk) and stores the raw
   // accumulators to partial[z][M][N]; splitk_reduce_kernel adds the slices in order + epilogue.
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
@@ -195,6 +195,42 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   }
 
   // ---- epilogue
+  if (wide_store) {
+    // Row-major 16-B stores: each accumulator tile (column on the lane, rows in registers) is turned
+    // through a per-wave LDS tile so that a store instruction writes 8 rows x 128 contiguous bytes
+    // (dwordx4 per lane) instead of 2 x 128 B with one dword per lane -- 4x fewer store instructions
+    // on the output-bound GEMMs (dz = g Wf^T writes 9*Cin floats per node).
+    __shared__ __attribute__((aligned(16))) float Es[4][32][36];
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Es[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int c4 = (lane & 7) * 4;
+        const int col = n0 + (wn * TN + j) * 32 + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && col < N) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int rr = pass * 8 + (lane >> 3);
+          const int row = m0 + (wm * TM + i) * 32 + rr;
+          float4 v = *reinterpret_cast<const float4*>(&Es[wave][rr][c4]);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+          v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+          if (row < M && col < N) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -458,7 +494,8 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
     dim3 grid(cdiv(M, BM_), cdiv(N, BN_), slices);                                                              \
     gemm_nn_kernel<WM, WN, TM_, TN_, BK_, FAST_><<<grid, block, 0, s>>>(A, lda, B, ldb, transB, C, ldc, M, N, K, \
                                                                 ep.bias,                                        \
-                                                           ep.slope, ep.C1, ep.split, ep.ldc1, k_chunk, partial); \
+                                                           ep.slope, ep.C1, ep.split, ep.ldc1, k_chunk, partial,  \
+                                                           wide);                                                \
   } while (0)
   // Few rows (coarse graph levels): shrink the block tile so the grid still covers the 256 CUs, and
   // split K across blockIdx.z when even the small tiles leave CUs idle.
@@ -485,6 +522,9 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
     if (slices > 1 && (size_t)slices * M * N * sizeof(float) <= ep.ws_bytes) partial = (float*)ep.ws;
     else { slices = 1; k_chunk = K; }
   }
+  // 16-B row stores need a plain, aligned, 4-float-granular output
+  const int wide = (partial == nullptr && ep.C1 == nullptr && (ldc & 3) == 0 && (N & 3) == 0 &&
+                    (((uintptr_t)C) & 15) == 0 && (ep.bias == nullptr || (((uintptr_t)ep.bias) & 15) == 0)) ? 1 : 0;
   if (big_blocks >= 384) {
     if (N > 64)
       GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
