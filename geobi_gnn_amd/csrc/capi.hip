@@ -221,9 +221,9 @@ int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const in
                           float* out, int32_t* arg, void* stream) {
   return segment_max_fwd(x, C, segptr, members, nseg, out, arg, S(stream));
 }
-int geobi_segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
-                          void* stream) {
-  return segment_max_bwd(gout, arg, C, nseg, n_fine, gx, S(stream));
+int geobi_segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, int C, int64_t nseg,
+                          int64_t n_fine, float* gx, void* stream) {
+  return segment_max_bwd(gout, arg, seg, C, nseg, n_fine, gx, S(stream));
 }
 int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
                       float* out, void* stream) {

@@ -111,16 +111,30 @@ __global__ void match_round_kernel(const int* __restrict__ rowptr, const int* __
   prop_next[u] = best;
 }
 
-// commit of the last round + count of nodes that are still undecided
+// commit of the last round + count of nodes that are still undecided; `final` (optional) receives the
+// clustering with the undecided nodes closed as singletons
 __global__ void match_commit_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
-                                    int* __restrict__ remaining) {
+                                    int* __restrict__ remaining, int* __restrict__ final) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  if (cluster[u] >= 0) return;
-  int v = prop[u];
-  if (v == -1) { cluster[u] = u; return; }
-  if (v >= 0 && prop[v] == u) cluster[u] = u < v ? u : v;
-  else atomicAdd(remaining, 1);
+  int c = cluster[u];
+  if (c < 0) {
+    int v = prop[u];
+    if (v == -1) c = u;
+    else if (v >= 0 && prop[v] == u) c = u < v ? u : v;
+    else atomicAdd(remaining, 1);
+    if (c >= 0) cluster[u] = c;
+  }
+  if (final) final[u] = c < 0 ? u : c;
+}
+
+__global__ void match_init_kernel(int N, int init, int* __restrict__ cluster, int* __restrict__ prop,
+                                  int* __restrict__ status) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0) *status = 0;
+  if (u >= N) return;
+  if (init) cluster[u] = -1;
+  prop[u] = -2;                                     // "no proposal information"
 }
 
 __global__ void match_finish_kernel(int N, const int* __restrict__ state, int* __restrict__ cluster) {
@@ -234,12 +248,21 @@ __global__ void segment_max_fwd_kernel(const float* __restrict__ x, int C, const
   arg[t] = bi;
 }
 
-__global__ void segment_max_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg, int C,
-                                       int64_t total, float* __restrict__ gx) {
+// gather form: fine row n receives the gradient of its segment where it was the arg-max (every
+// element of gx is written exactly once -> no zero-fill pass)
+__global__ void segment_max_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg,
+                                       const int* __restrict__ seg, int C, int64_t total, int nseg,
+                                       float* __restrict__ gx) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
-  int a = arg[t];
-  if (a >= 0) gx[(size_t)a * C + (t % C)] = gout[t];   // distinct (row, channel) per writer
+  int n = (int)(t / C), c = (int)(t % C);
+  int sg = seg[n];
+  float v = 0.f;
+  if (sg >= 0 && sg < nseg) {
+    size_t o = (size_t)sg * C + c;
+    if (arg[o] == n) v = gout[o];
+  }
+  gx[t] = v;
 }
 
 __global__ void segment_sum_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr,
@@ -328,6 +351,7 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow) {
   const int lane = threadIdx.x & 63;
   const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
   if (A >= nbound) return;
   const int nc = *ncount;
   if (A >= nc) { if (PASS == 0) cnt[A] = 0; return; }
@@ -414,6 +438,58 @@ __global__ void gather_f32_kernel(const float* __restrict__ src, const int* __re
   if (i < n) { int k = idx[i]; dst[i] = k >= 0 ? src[k] : 0.f; }
 }
 
+// Exclusive scan of up to a few hundred thousand ints in ONE launch (one 1024-thread block walking the
+// array with a running carry).  The graph levels of this path have <= ~10^5 nodes, where two rocPRIM
+// launches (init + lookback) cost more in launch latency than the scan itself.
+__global__ __launch_bounds__(1024) void small_exclusive_scan_kernel(const int* __restrict__ in, int* __restrict__ out,
+                                                                    int64_t n) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 4096) {
+    // 4 consecutive elements per thread
+    const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (i0 + q < n) ? in[i0 + q] : 0;
+    const int tsum = v[0] + v[1] + v[2] + v[3];
+    int inc = tsum;                                   // inclusive scan of thread sums inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += wsum[w];
+    int ex = carry_s + woff + inc - tsum;             // exclusive prefix of this thread's first element
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i0 + q < n) out[i0 + q] = ex;
+      ex += v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += total;
+    __syncthreads();
+  }
+}
+
+constexpr int64_t kSmallScan = 1 << 18;
+
+static hipError_t exclusive_scan_int(void* temp, size_t& tb, const int* in, int* out, int64_t n, hipStream_t s) {
+  if (n <= kSmallScan) {
+    if (temp == nullptr) { tb = 16; return hipSuccess; }
+    small_exclusive_scan_kernel<<<1, 1024, 0, s>>>(in, out, n);
+    return hipGetLastError();
+  }
+  return rocprim::exclusive_scan(temp, tb, in, out, 0, (size_t)n, rocprim::plus<int>(), s, false);
+}
+
 template <typename T>
 size_t scan_temp_bytes(int64_t n) {
   size_t tb = 0;
@@ -474,22 +550,16 @@ int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, 
   int* prop0 = a.take<int>(N);
   int* prop1 = a.take<int>(N);
   GEOBI_REQUIRE(a.ok() && prop0, "match: workspace too small");
-  if (init) GEOBI_HIP(hipMemsetAsync(cluster, 0xff, sizeof(int) * N, s));
-  GEOBI_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
-  GEOBI_HIP(hipMemsetAsync(prop0, 0xfe, sizeof(int) * N, s));     // 0xfefefefe < -1: "no information"
   int blocks = cdiv(N, 256);
+  match_init_kernel<<<blocks, 256, 0, s>>>((int)N, init, cluster, prop0, status);
   int* pp = prop0;
   int* pn = prop1;
   for (int r = 0; r < rounds; ++r) {
     match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, cluster, pn);
     int* t = pp; pp = pn; pn = t;
   }
-  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status);
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status, cluster_final);
   GEOBI_LAUNCH_OK();
-  if (cluster_final) {
-    match_finish_kernel<<<blocks, 256, 0, s>>>((int)N, cluster, cluster_final);
-    GEOBI_LAUNCH_OK();
-  }
   return 0;
 }
 
@@ -510,7 +580,7 @@ int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* c
   GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int) * N, s));
   rep_flag_kernel<<<blocks, 256, 0, s>>>(cluster, (int)N, flag);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, flag, rank, 0, (size_t)N, rocprim::plus<int>(), s, false));
+  GEOBI_HIP(exclusive_scan_int(temp, tb, flag, rank, N, s));
   relabel_apply_kernel<<<blocks, 256, 0, s>>>(cluster, flag, rank, (int)N, cnew, count);
   GEOBI_LAUNCH_OK();
   return 0;
@@ -558,7 +628,7 @@ int segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_
   pair_count_kernel<<<cdiv(nseg, 256), 256, 0, s>>>(cnew, raw, (int)N, (int)nseg, cnt);
   pair_mark_kernel<<<cdiv(N, 256), 256, 0, s>>>(cnew, raw, (int)N, cnt);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, segptr, 0, (size_t)nseg, rocprim::plus<int>(), s, false));
+  GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, segptr, nseg, s));
   pair_fill_kernel<<<cdiv(N, 256), 256, 0, s>>>(cnew, raw, (int)N, (int)nseg, segptr, members);
   GEOBI_LAUNCH_OK();
   return 0;
@@ -575,7 +645,7 @@ int segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const i
   GEOBI_REQUIRE(a.ok() && cnt, "segment_csr_compose: workspace too small");
   compose_count_kernel<<<cdiv(nseg2, 256), 256, 0, s>>>(segptr1, segptr2, members2, (int)nseg2, cnt);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, segptr12, 0, (size_t)nseg2, rocprim::plus<int>(), s, false));
+  GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, segptr12, nseg2, s));
   compose_fill_kernel<<<cdiv(nseg2, 256), 256, 0, s>>>(segptr1, members1, segptr2, members2, (int)nseg2,
                                                        (int)n_fine, segptr12, members12);
   GEOBI_LAUNCH_OK();
@@ -590,11 +660,10 @@ int segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t*
   return 0;
 }
 
-int segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
-                    hipStream_t s) {
-  GEOBI_HIP(hipMemsetAsync(gx, 0, sizeof(float) * n_fine * C, s));
-  if (nseg <= 0) return 0;
-  segment_max_bwd_kernel<<<cdiv(nseg * C, 256), 256, 0, s>>>(gout, arg, C, nseg * C, gx);
+int segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, int C, int64_t nseg, int64_t n_fine,
+                    float* gx, hipStream_t s) {
+  if (n_fine <= 0) return 0;
+  segment_max_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, arg, seg, C, n_fine * C, (int)nseg, gx);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -639,12 +708,11 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
   size_t tb = scan_temp_bytes<int>(nbound + 1);
   void* temp = a.take<char>(tb ? tb : 1);
   GEOBI_REQUIRE(a.ok() && cnt, "pool_edge_rows: workspace too small");
-  GEOBI_HIP(hipMemsetAsync(cnt + nbound, 0, sizeof(int), s));
   int blocks = cdiv(nbound, 4);
   pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
                                                    nullptr, nullptr, nullptr, nullptr, overflow);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::exclusive_scan(temp, tb, cnt, rowptr_c, 0, (size_t)(nbound + 1), rocprim::plus<int>(), s, false));
+  GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
   pool_edge_rows_kernel<1><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
                                                    rowptr_c, row_c, col_c, w_c, overflow);
   pool_rows_total_kernel<<<1, 64, 0, s>>>(rowptr_c, (int)nbound, count);
@@ -687,7 +755,7 @@ int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const
                                       s, false));
   pool_edge_heads_kernel<<<blocks, 256, 0, s>>>(k_out, E, head);
   GEOBI_LAUNCH_OK();
-  GEOBI_HIP(rocprim::exclusive_scan(t_scan, tb_scan, head, rank, 0, (size_t)E, rocprim::plus<int>(), s, false));
+  GEOBI_HIP(exclusive_scan_int(t_scan, tb_scan, head, rank, E, s));
   pool_edge_emit_kernel<<<blocks, 256, 0, s>>>(k_out, v_out, head, rank, w, E, row_c, col_c, w_c, ukeys, count,
                                                bits);
   GEOBI_LAUNCH_OK();

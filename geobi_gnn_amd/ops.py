@@ -155,7 +155,7 @@ class SegmentMaxFn(Function):
         L.call('geobi_segment_max_fwd', L.ptr(x), C, L.ptr(sidx.segptr), L.ptr(sidx.members), sidx.nseg, L.ptr(out),
                L.ptr(arg), L.stream())
         ctx.save_for_backward(arg)
-        ctx.n_fine = x.shape[0]
+        ctx.n_fine, ctx.sidx = x.shape[0], sidx
         return out
 
     @staticmethod
@@ -164,7 +164,8 @@ class SegmentMaxFn(Function):
         gout = _f32c(gout)
         nseg, C = gout.shape
         gx = torch.empty((ctx.n_fine, C), dtype=torch.float32, device=gout.device)
-        L.call('geobi_segment_max_bwd', L.ptr(gout), L.ptr(arg), C, nseg, ctx.n_fine, L.ptr(gx), L.stream())
+        L.call('geobi_segment_max_bwd', L.ptr(gout), L.ptr(arg), L.ptr(ctx.sidx.seg), C, nseg, ctx.n_fine, L.ptr(gx),
+               L.stream())
         return gx, None
 
 

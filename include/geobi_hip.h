@@ -130,8 +130,8 @@ int geobi_segment_csr_compose(const int32_t* segptr1, const int32_t* members1, c
                               int32_t* members12, void* ws, size_t ws_bytes, void* stream);
 int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
                           float* out, int32_t* arg, void* stream);
-int geobi_segment_max_bwd(const float* gout, const int32_t* arg, int C, int64_t nseg, int64_t n_fine, float* gx,
-                          void* stream);
+int geobi_segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, int C, int64_t nseg,
+                          int64_t n_fine, float* gx, void* stream);
 int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
                       float* out, void* stream);
 int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine,
