@@ -133,7 +133,7 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
 
 
 def _pool_features(x, sidx, pool_type):
-    return ops.SegmentMaxFn.apply(x, sidx) if pool_type == 'max' else ops.SegmentMeanFn.apply(x, sidx)
+    return ops.apply_op(ops.SegmentMaxFn if pool_type == 'max' else ops.SegmentMeanFn, x, sidx)
 
 
 def _compose(clusts):
@@ -243,7 +243,7 @@ class PoolingLayer(nn.Module):
                 sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
             sidxs.append(sidx)
             x = _pool_features(x, sidx, self.pool_type)
-            pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+            pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
             edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
             g, edge_weight = g_c, w_c
             if g.E == 0:
@@ -263,7 +263,7 @@ class PoolingLayer(nn.Module):
     def unpooling(self, x):
         if self.unpooling_indices is None:
             return x
-        return ops.UnpoolFn.apply(x, self._unpool_index)
+        return ops.apply_op(ops.UnpoolFn, x, self._unpool_index)
 
 
 # ------------------------------------------------------------------------ functional API
@@ -302,7 +302,7 @@ def pooling(data, p_type='max', level=2, wei_type=0):
         cnew, g_c, w_c, _, sidx = _coarsen(g, w)
         clusts.append(cnew)
         x = _pool_features(x, sidx, p_type)
-        pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+        pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
         g, w = g_c, w_c
         if g.E == 0:
             break
@@ -334,7 +334,7 @@ def pooling_run(data, pool_info, p_type='max'):
         nc = int(clust.max().item()) + 1
         sidx = ops.SegmentIndex(c32, nc)
         x = _pool_features(x, sidx, p_type)
-        pos = None if pos is None else ops.SegmentMeanFn.apply(pos, sidx)
+        pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
         rowptr_c, row_c, col_c, _, count = _pool_edge_raw(c32, g, None)
         ec = int(count.item())
         g = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec])

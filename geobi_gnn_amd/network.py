@@ -85,23 +85,59 @@ class DualGNN(nn.Module):
         self.fc_f2 = nn.Linear(1024, 3)
 
     def forward(self, dual_data):
+        """(data_v, data_f) -> (verts [V,3], unit normals [F,3], None)   (network.py:318-343).
+
+        The whole network is one autograd node (DualGNNFn): the ~70 differentiable ops inside run
+        through ops.Tape, which replays their backward passes in reverse order -- same kernels, no
+        per-op autograd overhead."""
         data_v, data_f = dual_data
         L.require_device(data_v.x, 'data_v.x')
+        params = [p for p in self.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            verts, normals = DualGNNFn.apply(self, data_v, data_f, *params)
+        else:
+            with torch.no_grad():
+                verts, normals, _ = self._forward_impl(data_v, data_f, ops.Tape(record=False))
+        return verts, normals, None
+
+    def _forward_impl(self, data_v, data_f, tape):
         x_v0 = data_v.x.contiguous()          # xyz = x[:, :3] is read in place as the head's residual
         dd = data_v.depth_direction if self.force_depth else None
+        with ops.use_tape(tape):
+            feat_v = self.gnn_v(data_v)
+            verts = ops.apply_op(ops.HeadFn, feat_v, self.fc_v1.weight, self.fc_v1.bias, self.fc_v2.weight,
+                                 self.fc_v2.bias, 0, dd, x_v0)
+            # new node feature of the facet graph: centroid + normal of the PREDICTED geometry
+            fv32, corner_index = _fv_index(data_f, verts.shape[0])
+            data_f.x = ops.apply_op(ops.FaceGeomFn, verts, data_f.x, fv32, corner_index)
+            feat_f = self.gnn_f(data_f)
+            normals = ops.apply_op(ops.HeadFn, feat_f, self.fc_f1.weight, self.fc_f1.bias, self.fc_f2.weight,
+                                   self.fc_f2.bias, 1, None, None)
+        return verts, normals, tape
 
-        feat_v = self.gnn_v(data_v)
-        verts = ops.HeadFn.apply(feat_v, self.fc_v1.weight, self.fc_v1.bias, self.fc_v2.weight, self.fc_v2.bias,
-                                 0, dd, x_v0)
 
-        # new node feature of the facet graph: centroid + normal of the PREDICTED geometry
-        fv32, corner_index = _fv_index(data_f, verts.shape[0])
-        data_f.x = ops.FaceGeomFn.apply(verts, data_f.x, fv32, corner_index)
+class DualGNNFn(torch.autograd.Function):
+    """DualGNN as a single autograd node.  Inputs after the three leading objects are the module's
+    parameters (so autograd routes their gradients); the backward replays the op tape."""
 
-        feat_f = self.gnn_f(data_f)
-        normals = ops.HeadFn.apply(feat_f, self.fc_f1.weight, self.fc_f1.bias, self.fc_f2.weight, self.fc_f2.bias,
-                                   1, None, None)
-        return verts, normals, None
+    @staticmethod
+    def forward(ctx, net, data_v, data_f, *params):
+        tape = ops.Tape(record=True)
+        verts, normals, _ = net._forward_impl(data_v, data_f, tape)
+        ctx.tape, ctx.verts, ctx.normals = tape, verts, normals
+        ctx.param_ids = [id(p) for p in params]
+        return verts, normals
+
+    @staticmethod
+    def backward(ctx, g_verts, g_normals):
+        seeds = {}
+        if g_verts is not None:
+            seeds[id(ctx.verts)] = g_verts.contiguous()
+        if g_normals is not None:
+            seeds[id(ctx.normals)] = g_normals.contiguous()
+        leaf = ctx.tape.backward(seeds)
+        ctx.tape = ctx.verts = ctx.normals = None
+        return (None, None, None) + tuple(leaf.get(k) for k in ctx.param_ids)
 
 
 # ---------------------------------------------------------------------------------------

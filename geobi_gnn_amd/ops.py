@@ -13,6 +13,88 @@ LEAK = 0.2
 HP = 12   # GEOBI_HEAD_STRIDE
 
 
+# ----------------------------------------------------------------------------- op tape
+# DualGNN.forward issues ~70 differentiable ops per step.  Going through torch.autograd for each costs
+# ~15 us of host time per node (Function.apply, graph bookkeeping, engine thread hops) -- more than
+# the kernels of the coarse levels take.  Inside DualGNN the same Function classes are therefore
+# driven through a minimal reverse-mode tape: the whole network is ONE autograd node
+# (network.DualGNNFn) and the tape replays the per-op `backward`s in reverse order.  Outside of it
+# (FeaStConv / PoolingLayer used on their own) the ops are ordinary autograd Functions.
+class _TapeCtx(object):
+    __slots__ = ('needs_input_grad', 'saved_tensors', '__dict__')
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class Tape(object):
+    """Reverse-mode tape over the Function classes of this module (forward called in no-grad mode)."""
+
+    def __init__(self, record=True):
+        self.record = record
+        self.nodes = []
+        self.live = set()              # ids of intermediate tensors that carry a gradient
+
+    def needs(self, a):
+        return torch.is_tensor(a) and a.is_floating_point() and (a.requires_grad or id(a) in self.live)
+
+    def apply(self, fn, *args):
+        needs = tuple(self.needs(a) for a in args)
+        ctx = _TapeCtx(needs)
+        out = fn.forward(ctx, *args)
+        if self.record and any(needs):
+            self.nodes.append((fn, ctx, args, out))
+            self.live.add(id(out))
+        return out
+
+    def backward(self, seeds):
+        """seeds: {id(tensor): grad}.  Returns {id(leaf tensor): grad} for leaves with requires_grad."""
+        grads = dict(seeds)
+        leaf = {}
+        for fn, ctx, args, out in reversed(self.nodes):
+            g = grads.pop(id(out), None)
+            if g is None:
+                continue
+            gins = fn.backward(ctx, g)
+            for a, gi in zip(args, gins):
+                if gi is None or not torch.is_tensor(a):
+                    continue
+                k = id(a)
+                if k in self.live:
+                    grads[k] = gi if k not in grads else grads[k] + gi
+                elif a.requires_grad:
+                    leaf[k] = gi if k not in leaf else leaf[k] + gi
+        self.nodes = []
+        return leaf
+
+
+_ACTIVE_TAPE = [None]
+
+
+def apply_op(fn, *args):
+    """Run a Function through the active tape (inside DualGNN) or through torch.autograd."""
+    tape = _ACTIVE_TAPE[0]
+    return tape.apply(fn, *args) if tape is not None else fn.apply(*args)
+
+
+class use_tape(object):
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.prev = _ACTIVE_TAPE[0]
+        _ACTIVE_TAPE[0] = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        _ACTIVE_TAPE[0] = self.prev
+        return False
+
+
 def _direct_grad(p):
     """Gradient buffer the kernels may write into directly.
 
@@ -96,7 +178,7 @@ class FeastConvFn(Function):
 
 
 def feast_conv(x, graph, lin_w, u_w, c, bias, slope=1.0, x2=None):
-    return FeastConvFn.apply(x, x2, lin_w, u_w, c, bias, graph, slope)
+    return apply_op(FeastConvFn, x, x2, lin_w, u_w, c, bias, graph, slope)
 
 
 # ------------------------------------------------------------------ inverse lists / pooling
