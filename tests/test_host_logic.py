@@ -179,3 +179,68 @@ def test_data_parallel_gloo_world2(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
+
+
+def test_op_tape_matches_autograd_on_a_dag():
+    """ops.Tape (the reverse-mode tape DualGNN runs its ~70 ops through) against torch.autograd on a
+    small DAG with a tensor used twice, a two-output-gradient op and a branch without gradient."""
+    from torch.autograd import Function
+    from geobi_gnn_amd import ops
+
+    class Scale(Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            return g * w, (g * x).sum(0, keepdim=True) if ctx.needs_input_grad[1] else None
+
+    class AddPair(Function):
+        @staticmethod
+        def forward(ctx, a, b, k):
+            ctx.k = k
+            return a + k * b
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, ctx.k * g, None
+
+    torch.manual_seed(0)
+    x = torch.randn(5, 3)
+    w1 = torch.randn(1, 3, requires_grad=True)
+    w2 = torch.randn(1, 3, requires_grad=True)
+    const = torch.randn(5, 3)
+
+    def graph(apply):
+        h = apply(Scale, x, w1)              # x needs no grad
+        a = apply(Scale, h, w2)              # h used twice below
+        b = apply(AddPair, h, a, 2.0)
+        dead = apply(Scale, const, const[:1])   # no gradient flows here
+        return apply(AddPair, b, h, -0.5), dead
+
+    out_ref, _ = graph(lambda fn, *a: fn.apply(*a))
+    g = torch.randn_like(out_ref)
+    out_ref.backward(g)
+    ref = (w1.grad.clone(), w2.grad.clone())
+
+    tape = ops.Tape(record=True)
+    with torch.no_grad():
+        out_t, dead = graph(tape.apply)
+    assert torch.equal(out_t, out_ref.detach())
+    assert len(tape.nodes) == 4                                   # the dead branch was not recorded
+    leaf = tape.backward({id(out_t): g})
+    assert torch.allclose(leaf[id(w1)], ref[0], atol=1e-6) and torch.allclose(leaf[id(w2)], ref[1], atol=1e-6)
+    assert tape.nodes == []
+    # a tape that does not record (inference) keeps nothing alive
+    t2 = ops.Tape(record=False)
+    with torch.no_grad():
+        graph(t2.apply)
+    assert t2.nodes == []
+    # apply_op falls back to torch.autograd when no tape is active and uses the active one otherwise
+    assert ops._ACTIVE_TAPE[0] is None
+    with ops.use_tape(tape):
+        assert ops._ACTIVE_TAPE[0] is tape
+    assert ops._ACTIVE_TAPE[0] is None
