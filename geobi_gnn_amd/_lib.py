@@ -125,3 +125,18 @@ def call(name, *args):
         fn = _fn_cache[name] = getattr(lib(), name)
     if fn(*args) != 0:
         check(1, name)
+
+
+_size_cache = {}
+
+
+def size_query(name, *args):
+    """Memoised host-side size queries (geobi_*_ws_bytes, geobi_feast_ldz): pure functions of their
+    integer arguments, called once per op otherwise (~3 us of ctypes each)."""
+    key = (name,) + args
+    v = _size_cache.get(key)
+    if v is None:
+        if len(_size_cache) > 8192:
+            _size_cache.clear()
+        v = _size_cache[key] = getattr(lib(), name)(*args)
+    return v

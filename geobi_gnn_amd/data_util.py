@@ -37,7 +37,7 @@ def update_position2(points, fv_indices, vf_indices, face_normals, n_iter=20, de
     dd = None if depth_direction is None else depth_direction.detach().float().contiguous()
     V, F = pts.shape[0], fv32.shape[0]
     out = torch.empty_like(pts)
-    ws = L.workspace(L.lib().geobi_update_position_ws_bytes(V, F), pts.device)
+    ws = L.workspace(L.size_query('geobi_update_position_ws_bytes', V, F), pts.device)
     L.call('geobi_update_position2', L.ptr(pts), L.ptr(fv32), L.ptr(vf32), vf32.shape[1], L.ptr(nrm), L.ptr(dd), V, F,
            int(n_iter), L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
     return out

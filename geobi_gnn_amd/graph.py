@@ -46,7 +46,7 @@ class Graph(object):
         g.rowptr_out = torch.empty(g.N + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(E0, 1), dtype=torch.int32, device=dev)
         eid = torch.empty(max(E0, 1), dtype=torch.int32, device=dev)
-        nb = L.lib().geobi_csr_ws_bytes(E0, g.N)
+        nb = L.size_query('geobi_csr_ws_bytes', E0, g.N)
         ws = L.workspace(nb, dev)
         L.call('geobi_csr_from_coo', L.ptr(ei[0]), L.ptr(ei[1]), E0, g.N, 1, L.ptr(g.rowptr_out), L.ptr(col),
                L.ptr(eid), L.ptr(ws), ws.numel(), L.stream())
@@ -103,7 +103,7 @@ class Graph(object):
             self.col_in = torch.empty(cap, dtype=torch.int32, device=dev)[:self.E]
             pos_t = torch.empty(cap, dtype=torch.int32, device=dev)[:self.E]
             self.pos_in = torch.empty(cap, dtype=torch.int32, device=dev)[:self.E]
-            ws = L.workspace(L.lib().geobi_csr_ws_bytes(self.E, self.N), dev)
+            ws = L.workspace(L.size_query('geobi_csr_ws_bytes', self.E, self.N), dev)
             L.call('geobi_csr_transpose', L.ptr(self.rowptr_out), L.ptr(self.col_out), self.N, self.E,
                    L.ptr(self.rowptr_in), L.ptr(self.col_in), L.ptr(pos_t), L.ptr(self.pos_in), L.ptr(ws),
                    ws.numel(), L.stream())

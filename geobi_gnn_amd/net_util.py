@@ -41,7 +41,7 @@ def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None, status=None
     cluster = torch.empty(graph.N, dtype=torch.int32, device=dev)
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = L.workspace(L.lib().geobi_match_ws_bytes(graph.N), dev)
+    ws = L.workspace(L.size_query('geobi_match_ws_bytes', graph.N), dev)
     w = None if weight_sorted is None else weight_sorted.contiguous()
     L.call('geobi_match_heavy_edge', L.ptr(graph.rowptr_out), L.ptr(graph.col_out), L.ptr(w), graph.N, rounds,
            1 if init else 0, L.ptr(state), L.ptr(cluster), L.ptr(status), L.ptr(ws), ws.numel(), L.stream())
@@ -55,7 +55,7 @@ def relabel(cluster32, count=None):
     cnew = torch.empty(n, dtype=torch.int32, device=dev)
     if count is None:
         count = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = L.workspace(L.lib().geobi_relabel_ws_bytes(n), dev)
+    ws = L.workspace(L.size_query('geobi_relabel_ws_bytes', n), dev)
     L.call('geobi_relabel_compact', L.ptr(cluster32), n, L.ptr(cnew), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
     return cnew, count
 
@@ -71,7 +71,7 @@ def _pool_edge_raw(cnew32, graph, weight_sorted, count=None):
     w_c = None if weight_sorted is None else torch.empty(cap, dtype=torch.float32, device=dev)
     if count is None:
         count = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = L.workspace(L.lib().geobi_pool_edge_ws_bytes(E), dev)
+    ws = L.workspace(L.size_query('geobi_pool_edge_ws_bytes', E), dev)
     L.call('geobi_pool_edge', L.ptr(cnew32), L.ptr(graph.ensure_rows()), L.ptr(graph.col_out),
            L.ptr(None if weight_sorted is None else weight_sorted.contiguous()), E, nmax, L.ptr(rowptr_c),
            L.ptr(row_c), L.ptr(col_c), L.ptr(w_c), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
@@ -86,7 +86,7 @@ def _pool_edge_rows(cnew32, sidx, graph, weight_sorted, ncount, count, overflow)
     row_c = torch.empty(cap, dtype=torch.int32, device=dev)
     col_c = torch.empty(cap, dtype=torch.int32, device=dev)
     w_c = None if weight_sorted is None else torch.empty(cap, dtype=torch.float32, device=dev)
-    ws = L.workspace(L.lib().geobi_pool_edge_rows_ws_bytes(graph.N), dev)
+    ws = L.workspace(L.size_query('geobi_pool_edge_rows_ws_bytes', graph.N), dev)
     L.call('geobi_pool_edge_rows', L.ptr(cnew32), L.ptr(sidx.segptr), L.ptr(sidx.members), L.ptr(graph.rowptr_out),
            L.ptr(graph.col_out), L.ptr(None if weight_sorted is None else weight_sorted.contiguous()), L.ptr(ncount),
            graph.N, L.ptr(rowptr_c), L.ptr(row_c), L.ptr(col_c), L.ptr(w_c), L.ptr(count), L.ptr(overflow),

@@ -135,11 +135,11 @@ class FeastConvFn(Function):
             raise L.GeobiError('FeaStConv: parameter shapes do not match heads=9, in=%d, out=%d' % (Cin, Cout))
         dev = xa.device
         lib = L.lib()
-        ldz = lib.geobi_feast_ldz(Cin)
+        ldz = L.size_query('geobi_feast_ldz', Cin)
         out = torch.empty((N, Cout), dtype=torch.float32, device=dev)
         p = torch.empty((N, HP), dtype=torch.float32, device=dev)
         z = torch.empty((N, ldz), dtype=torch.float32, device=dev)
-        ws = L.workspace(lib.geobi_feast_fwd_ws_bytes(N, Cin, Cout), dev)
+        ws = L.workspace(L.size_query('geobi_feast_fwd_ws_bytes', N, Cin, Cout), dev)
         L.call('geobi_feast_fwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(lin_w), L.ptr(u_w), L.ptr(c), L.ptr(bias), Cout, float(slope), L.ptr(out), L.ptr(p), L.ptr(z),
                L.ptr(ws), ws.numel(), L.stream())
@@ -169,7 +169,7 @@ class FeastConvFn(Function):
             dlin, du, dc = torch.empty_like(lin_w), torch.empty_like(u_w), torch.empty_like(c)
             dbias = torch.empty(Cout, dtype=torch.float32, device=dev)
             ret = (dlin, du, dc, dbias)
-        ws = L.workspace(L.lib().geobi_feast_bwd_ws_bytes(N, g.E, Cin, Cout), dev)
+        ws = L.workspace(L.size_query('geobi_feast_bwd_ws_bytes', N, g.E, Cin, Cout), dev)
         L.call('geobi_feast_bwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
                ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
@@ -194,7 +194,7 @@ class SegmentIndex(object):
         self.segptr = torch.empty(self.nseg + 1, dtype=torch.int32, device=dev)
         self.members = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)[:self.n]
         if build:       # general path: radix sort of (segment, member) keys
-            ws = L.workspace(L.lib().geobi_segment_csr_ws_bytes(self.n), dev)
+            ws = L.workspace(L.size_query('geobi_segment_csr_ws_bytes', self.n), dev)
             L.call('geobi_segment_csr', L.ptr(self.seg), self.n, self.nseg, L.ptr(self.segptr),
                    L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
 
@@ -203,7 +203,7 @@ class SegmentIndex(object):
         """Sort-free lists for a matching (clusters of <= 2 nodes, raw id = smaller member)."""
         self = SegmentIndex(cnew32, nseg, build=False)
         raw32 = raw32.contiguous()
-        ws = L.workspace(L.lib().geobi_segment_pairs_ws_bytes(self.nseg), cnew32.device)
+        ws = L.workspace(L.size_query('geobi_segment_pairs_ws_bytes', self.nseg), cnew32.device)
         L.call('geobi_segment_csr_pairs', L.ptr(self.seg), L.ptr(raw32), self.n, self.nseg, L.ptr(self.segptr),
                L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
         return self
@@ -218,7 +218,7 @@ class SegmentIndex(object):
     def compose(first, second, composed_seg32):
         """Lists of fine -> coarse for `composed_seg32 = second.seg[first.seg]`."""
         self = SegmentIndex(composed_seg32, second.nseg, build=False)
-        ws = L.workspace(L.lib().geobi_segment_pairs_ws_bytes(self.nseg), composed_seg32.device)
+        ws = L.workspace(L.size_query('geobi_segment_pairs_ws_bytes', self.nseg), composed_seg32.device)
         L.call('geobi_segment_csr_compose', L.ptr(first.segptr), L.ptr(first.members), L.ptr(second.segptr),
                L.ptr(second.members), self.nseg, self.n, L.ptr(self.segptr), L.ptr(self.members), L.ptr(ws),
                ws.numel(), L.stream())
@@ -379,7 +379,7 @@ class HeadFn(Function):
             dw1, db1 = torch.empty_like(w1), torch.empty(K, dtype=torch.float32, device=dev)
             dw2, db2 = torch.empty_like(w2), torch.empty(nout, dtype=torch.float32, device=dev)
             ret = (dw1, db1, dw2, db2)
-        ws = L.workspace(L.lib().geobi_head_bwd_ws_bytes(N, Cin, K), dev)
+        ws = L.workspace(L.size_query('geobi_head_bwd_ws_bytes', N, Cin, K), dev)
         L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), L.ptr(b1), K, L.ptr(w2), nout, LEAK, ctx.mode,
                L.ptr(dd), L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2),
                L.ptr(db2), L.ptr(ws), ws.numel(), L.stream())
@@ -399,7 +399,7 @@ class RowLossFn(Function):
         w = None if w is None else _f32c(w)
         n = a.shape[0]
         out = torch.empty(1, dtype=torch.float32, device=a.device)
-        ws = L.workspace(L.lib().geobi_row_loss_ws_bytes(n), a.device)
+        ws = L.workspace(L.size_query('geobi_row_loss_ws_bytes', n), a.device)
         L.call('geobi_row_loss_fwd', L.ptr(a), L.ptr(b), L.ptr(w), n, int(kind), float(scale), L.ptr(out), L.ptr(ws),
                ws.numel(), L.stream())
         ctx.kind, ctx.scale, ctx.has_w = int(kind), float(scale), w is not None
