@@ -462,7 +462,9 @@ TnPlan plan_tn(int I, int J, int64_t M) {
   p.tiles_j = cdiv(J, 32 * p.tj);
   int tiles = p.tiles_i * p.tiles_j;
   int64_t want = 1536 / (tiles > 0 ? tiles : 1);     // target ~1.5k waves in flight (6 per CU)
-  int64_t max_slices = (M + 255) / 256;              // >= 256 nodes per slice
+  // >= 256 nodes per slice; coarse levels (few nodes) are latency-bound per wave, so they get shorter
+  // slices (>= 64 nodes) and more waves instead
+  int64_t max_slices = (M <= 32768 || tiles <= 3) ? (M + 63) / 64 : (M + 255) / 256;
   int64_t sl = want < 4 ? 4 : want;
   if (sl > max_slices) sl = max_slices;
   if (sl < 1) sl = 1;
