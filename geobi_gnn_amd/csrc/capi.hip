@@ -150,14 +150,14 @@ static int check_channels(const char* fn, int Cin, int Cout) {
 int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
                     const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
                     const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
-                    void* ws, size_t ws_bytes, void* stream) {
+                    float* wf, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c); NOTNULL(bias);
   NOTNULL(out); NOTNULL(p); NOTNULL(z);
   if (Cb > 0) NOTNULL(xb);
   if (E > 0) NOTNULL(col_in);
   GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
   return feast_fwd(xa, Cb > 0 ? xb : nullptr, Ca, Cb, N, E, rowptr_in, col_in, lin_w, u_w, c, bias, Cout, slope, out,
-                   p, z, ws, ws_bytes, S(stream));
+                   p, z, wf, ws, ws_bytes, S(stream));
 }
 
 size_t geobi_feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout) { return feast_bwd_ws_bytes(N, E, Cin, Cout); }
@@ -166,8 +166,8 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const int32_t* rowptr_in, const int32_t* col_in, const int32_t* rowptr_out,
                     const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
                     const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
-                    const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc, float* dbias,
-                    void* ws, size_t ws_bytes, void* stream) {
+                    const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
+                    float* dbias, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(rowptr_out); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c);
   NOTNULL(gout); NOTNULL(p); NOTNULL(z); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
   if (slope != 1.0f) NOTNULL(out);
@@ -175,7 +175,7 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
   if (E > 0) { NOTNULL(col_in); NOTNULL(col_out); NOTNULL(pos_in); }
   GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
   return feast_bwd(xa, Cb > 0 ? xb : nullptr, Ca, Cb, N, E, rowptr_in, col_in, rowptr_out, col_out, pos_in, lin_w,
-                   u_w, c, Cout, slope, out, gout, p, z, dxa, dxb, dlin_w, du_w, dc, dbias, ws, ws_bytes, S(stream));
+                   u_w, c, Cout, slope, out, gout, p, z, wf, dxa, dxb, dlin_w, du_w, dc, dbias, ws, ws_bytes, S(stream));
 }
 
 int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,

@@ -115,13 +115,14 @@ int feast_ldz(int Cin);
 size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
               const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
-              int Cout, float slope, float* out, float* p, float* z, void* ws, size_t ws_bytes, hipStream_t s);
+              int Cout, float slope, float* out, float* p, float* z, float* wf_out, void* ws, size_t ws_bytes,
+              hipStream_t s);
 size_t feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
 int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
               const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
-              const float* gout, const float* p, const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w,
-              float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+              const float* gout, const float* p, const float* z, const float* wf_saved, float* dxa, float* dxb,
+              float* dlin_w, float* du_w, float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
 // pool.hip
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
                     float* w_out, hipStream_t s);

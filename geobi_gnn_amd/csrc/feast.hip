@@ -505,13 +505,14 @@ size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) {
 
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
               const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
-              int Cout, float slope, float* out, float* p, float* z, void* ws, size_t ws_bytes, hipStream_t s) {
+              int Cout, float slope, float* out, float* p, float* z, float* wf_out, void* ws, size_t ws_bytes,
+              hipStream_t s) {
   const int Cin = Ca + Cb;
   GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_fwd: bad node count");
   GEOBI_REQUIRE(Cb == 0 || Ca == Cb, "feast_fwd: a split input must have two equal halves");
   const int Kp = feast_ldz(Cin);
   Arena a(ws, ws_bytes);
-  float* wf = a.take<float>((size_t)Kp * Cout);
+  float* wf = wf_out ? wf_out : a.take<float>((size_t)Kp * Cout);   // packed weights, kept for the backward
   const int fwd_slices = feast_fwd_slices(Kp, Cout);
   const size_t gws = gemm_nn_fixed_ws_bytes(N, Cout, fwd_slices);
   void* gemm_ws = a.take<char>(gws);
@@ -571,8 +572,8 @@ size_t feast_bwd_ws_bytes(int64_t N, int64_t Ecap, int Cin, int Cout) {
 int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
               const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
-              const float* gout, const float* p, const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w,
-              float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+              const float* gout, const float* p, const float* z, const float* wf_saved, float* dxa, float* dxb,
+              float* dlin_w, float* du_w, float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
   const int Cin = Ca + Cb;
   const int Kp = feast_ldz(Cin), ldr = feast_ldr(Cout);
   GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_bwd: bad node count");
@@ -598,12 +599,16 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, fk.side ? fk.side : s));
   }
   // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
-  pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
-  GEOBI_LAUNCH_OK();
+  const float* wf = wf_saved;
+  if (wf == nullptr) {     // not kept from the forward: repack
+    pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
+    GEOBI_LAUNCH_OK();
+    wf = b.wf;
+  }
   GemmEpilogue ep0;
   ep0.ws = b.gemm_ws;
   ep0.ws_bytes = b.gemm_bytes;
-  GEOBI_TRY(gemm_nn(g, Cout, b.wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
+  GEOBI_TRY(gemm_nn(g, Cout, wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
   int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,

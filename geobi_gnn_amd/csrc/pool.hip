@@ -348,10 +348,12 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     const int* __restrict__ cnew, const int* __restrict__ segptr, const int* __restrict__ members,
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ w,
     const int* __restrict__ ncount, int nbound, int* __restrict__ cnt, const int* __restrict__ rowptr_c,
-    int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow) {
+    int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow,
+    int* __restrict__ total) {
   const int lane = threadIdx.x & 63;
   const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
+  if (PASS == 1 && blockIdx.x == 0 && threadIdx.x == 0) *total = rowptr_c[nbound];
   if (A >= nbound) return;
   const int nc = *ncount;
   if (A >= nc) { if (PASS == 0) cnt[A] = 0; return; }
@@ -407,10 +409,6 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     col_c[pos] = key;
     if (w) w_c[pos] = (float)(sum / (double)len);
   }
-}
-
-__global__ void pool_rows_total_kernel(const int* __restrict__ rowptr_c, int nbound, int* __restrict__ count) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count = rowptr_c[nbound];
 }
 
 __global__ void pool_edge_rowptr_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ count, int nmax,
@@ -710,12 +708,11 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
   GEOBI_REQUIRE(a.ok() && cnt, "pool_edge_rows: workspace too small");
   int blocks = cdiv(nbound, 4);
   pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   nullptr, nullptr, nullptr, nullptr, overflow);
+                                                   nullptr, nullptr, nullptr, nullptr, overflow, nullptr);
   GEOBI_LAUNCH_OK();
   GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
   pool_edge_rows_kernel<1><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   rowptr_c, row_c, col_c, w_c, overflow);
-  pool_rows_total_kernel<<<1, 64, 0, s>>>(rowptr_c, (int)nbound, count);
+                                                   rowptr_c, row_c, col_c, w_c, overflow, count);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -139,17 +139,18 @@ class FeastConvFn(Function):
         out = torch.empty((N, Cout), dtype=torch.float32, device=dev)
         p = torch.empty((N, HP), dtype=torch.float32, device=dev)
         z = torch.empty((N, ldz), dtype=torch.float32, device=dev)
+        wf = torch.empty((ldz, Cout), dtype=torch.float32, device=dev)      # packed weights, reused by the backward
         ws = L.workspace(L.size_query('geobi_feast_fwd_ws_bytes', N, Cin, Cout), dev)
         L.call('geobi_feast_fwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(lin_w), L.ptr(u_w), L.ptr(c), L.ptr(bias), Cout, float(slope), L.ptr(out), L.ptr(p), L.ptr(z),
-               L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(wf), L.ptr(ws), ws.numel(), L.stream())
         ctx.graph, ctx.slope, ctx.has_b = g, float(slope), xb is not None
-        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z)
+        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z, wf)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        xa, xb, lin_w, u_w, c, out, p, z = ctx.saved_tensors
+        xa, xb, lin_w, u_w, c, out, p, z, wf = ctx.saved_tensors
         g = ctx.graph
         if not ctx.has_b:
             xb = None
@@ -172,7 +173,7 @@ class FeastConvFn(Function):
         ws = L.workspace(L.size_query('geobi_feast_bwd_ws_bytes', N, g.E, Cin, Cout), dev)
         L.call('geobi_feast_bwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
-               ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
+               ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(wf), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
                L.ptr(du), L.ptr(dc), L.ptr(dbias), L.ptr(ws), ws.numel(), L.stream())
         return (dxa, dxb) + ret + (None, None)
 

@@ -69,7 +69,9 @@ int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst
  *             out-edge e in the in-CSR.  Both without self loops (one per node is implied).
  *   lin_w [9*Cout, Cin], u_w [9, Cin], c [9], bias [Cout]   (PyG >= 2.0 state-dict layout)
  *   forward saves p [N, 12] (x u^T) and z [N, geobi_feast_ldz(Cin)] (aggregated features) for the
- *   backward; `out` after the activation is needed by the backward when slope != 1.
+ *   backward; `out` after the activation is needed by the backward when slope != 1.  wf (optional,
+ *   [geobi_feast_ldz(Cin), Cout]) receives the packed weights in the forward and, handed back to the
+ *   backward, saves repacking them (NULL: packed into the workspace on both sides).
  *   E = number of edges in the CSR (used for scratch sizing and byte accounting only).
  *   Supported channel counts: Cin, Cout in {6, 12, 32, 64, 128} (Cout: 32, 64, 128).           */
 int geobi_feast_ldz(int Cin);
@@ -77,15 +79,15 @@ size_t geobi_feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
 int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
                     const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
                     const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
-                    void* ws, size_t ws_bytes, void* stream);
+                    float* wf, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
 /* dxa/dxb may be NULL (input needs no gradient); dlin_w/du_w/dc/dbias are overwritten. */
 int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
                     const int32_t* rowptr_in, const int32_t* col_in, const int32_t* rowptr_out,
                     const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
                     const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
-                    const float* z, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc, float* dbias,
-                    void* ws, size_t ws_bytes, void* stream);
+                    const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
+                    float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- pooling ------------------
  * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10
