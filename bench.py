@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32), same table
 FREQ = 32                  # icosphere frequency: F = 20 480 faces
 BATCH = 4
 
@@ -96,6 +97,32 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
                                'achieved': round(total['bytes'] / (total['ms'] * 1e-3) / 1e9, 1),
                                'avg_us': round(total['ms'] * 1e3 / total['launches'], 2)},
     }
+
+
+def measure_mfma(net, bucket, opt, dv, df, steps=3):
+    """Second separate pass: the node-level GEMMs (z Wf, g Wf^T, r' W: gemm_nn; weight gradients:
+    gemm_tn) bracketed by HIP events, with the side stream off so that each is timed alone.
+    BASELINE.json's north_star asks for the MFMA utilisation of the node GEMM beside the HBM line."""
+    from geobi_gnn_amd import _lib as L
+    lib = L.lib()
+    lib.geobi_set_overlap(0)
+    lib.geobi_prof_enable(4)
+    for _ in range(steps):
+        train_step(net, bucket, opt, dv, df, collective=False)
+    torch.cuda.synchronize()
+    out = {'bound': 'mfma', 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'pmc': 'profiles/r01_pmc_gemm_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_mfma.py)'}
+    for name, tag in (('gemm_nn', 1), ('gemm_tn', 2)):
+        n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'prof_collect')
+        if n.value:
+            tf = fl.value / (ms.value * 1e-3) / 1e12
+            out[name] = {'launches_per_step': n.value // steps, 'avg_us': round(ms.value * 1e3 / n.value, 2),
+                         'gflop_per_step': round(fl.value / steps / 1e9, 2), 'achieved': round(tf, 1),
+                         'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    lib.geobi_prof_enable(0)
+    lib.geobi_set_overlap(1)
+    return out
 
 
 def host_cores():
@@ -234,6 +261,7 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             out['roofline'] = measure_roofline(net, bucket, opt, dv, df)
+            out['roofline_mfma'] = measure_mfma(net, bucket, opt, dv, df)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.freq)
     if world > 1:

@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int LDA_S = BM + 1;
   constexpr int LDB_S = BN + 4;
-  __shared__ float As[BK][LDA_S];
-  __shared__ float Bs[BK][LDB_S];
+  // one LDS block: the staging tiles, re-used by the wide-store epilogue once the k loop is over
+  constexpr int TILE_FLOATS = BK * LDA_S + BK * LDB_S;
+  constexpr int EPI_FLOATS = 4 * 32 * 36;
+  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS];
+  float (*As)[LDA_S] = reinterpret_cast<float (*)[LDA_S]>(smem);
+  float (*Bs)[LDB_S] = reinterpret_cast<float (*)[LDB_S]>(smem + BK * LDA_S);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -74,11 +78,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 4; ++i) ra[pass][i] = 0.f;
       if constexpr (FAST) {
-        const bool ok = row < BM && gm < M && gk < K;
+        // raw load from a clamped (always valid) address; the out-of-range select happens in
+        // store_tiles, i.e. after the MFMA section, so nothing waits on this load before the MFMAs
         const float* src = A + (size_t)min(gm, M - 1) * lda + min(gk, K - 4);
         float4 t = *reinterpret_cast<const float4*>(src);
-        ra[pass][0] = ok ? t.x : 0.f; ra[pass][1] = ok ? t.y : 0.f;
-        ra[pass][2] = ok ? t.z : 0.f; ra[pass][3] = ok ? t.w : 0.f;
+        ra[pass][0] = t.x; ra[pass][1] = t.y; ra[pass][2] = t.z; ra[pass][3] = t.w;
       } else if (row < BM && gm < M) {
         const float* src = A + (size_t)gm * lda + gk;
         if (a_vec && gk + 3 < K) {
@@ -102,11 +106,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
         int kk = q / QPR, nq = (q % QPR) * 4;
         int gk = k0 + kk, gn = n0 + nq;
         if constexpr (FAST) {
-          const bool ok = gk < K && gn < N;
           const float* src = B + (size_t)min(gk, K - 1) * ldb + min(gn, N - 4);
           float4 t = *reinterpret_cast<const float4*>(src);
-          rb[qi][0] = ok ? t.x : 0.f; rb[qi][1] = ok ? t.y : 0.f;
-          rb[qi][2] = ok ? t.z : 0.f; rb[qi][3] = ok ? t.w : 0.f;
+          rb[qi][0] = t.x; rb[qi][1] = t.y; rb[qi][2] = t.z; rb[qi][3] = t.w;
         } else if (gk < K) {
           const float* src = B + (size_t)gk * ldb + gn;
           if (b_vec && gn + 3 < N) {
@@ -122,11 +124,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
         int nn = q / KQ, kq = (q % KQ) * 4;
         int gn = n0 + nn, gk = k0 + kq;
         if constexpr (FAST) {
-          const bool ok = gn < N && gk < K;
           const float* src = B + (size_t)min(gn, N - 1) * ldb + min(gk, K - 4);
           float4 t = *reinterpret_cast<const float4*>(src);
-          rb[qi][0] = ok ? t.x : 0.f; rb[qi][1] = ok ? t.y : 0.f;
-          rb[qi][2] = ok ? t.z : 0.f; rb[qi][3] = ok ? t.w : 0.f;
+          rb[qi][0] = t.x; rb[qi][1] = t.y; rb[qi][2] = t.z; rb[qi][3] = t.w;
         } else if (gn < N) {
           const float* src = B + (size_t)gn * ldb + gk;
           if (b_vec && gk + 3 < K) {
@@ -142,14 +142,15 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int k0) {      // k0: the k-tile the registers were loaded for
 #pragma unroll
     for (int pass = 0; pass < A_PASSES; ++pass) {
       int row = tid / KQ + pass * A_ROWS;
       int kq = (tid % KQ) * 4;
       if (row < BM) {
+        const bool ok = !FAST || (m0 + row < M && k0 + kq < K);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) As[kq + i][row] = ra[pass][i];
+        for (int i = 0; i < 4; ++i) As[kq + i][row] = ok ? ra[pass][i] : 0.f;
       }
     }
 #pragma unroll
@@ -159,12 +160,14 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
       if (!transB) {
         constexpr int QPR = BN / 4;
         int kk = q / QPR, nq = (q % QPR) * 4;
+        const bool ok = !FAST || (k0 + kk < K && n0 + nq < N);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = rb[qi][i];
+        for (int i = 0; i < 4; ++i) Bs[kk][nq + i] = ok ? rb[qi][i] : 0.f;
       } else {
         int nn = q / KQ, kq = (q % KQ) * 4;
+        const bool ok = !FAST || (n0 + nn < N && k0 + kq < K);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = rb[qi][i];
+        for (int i = 0; i < 4; ++i) Bs[kq + i][nn] = ok ? rb[qi][i] : 0.f;
       }
     }
   };
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   const int k_hi = partial ? min(K, k_lo + k_chunk) : K;
   load_tiles(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
-    store_tiles();
+    store_tiles(k0);
     __syncthreads();
     if (k0 + BK < k_hi) load_tiles(k0 + BK);
     // ---- MFMA over the k-tile
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
     // through a per-wave LDS tile so that a store instruction writes 8 rows x 128 contiguous bytes
     // (dwordx4 per lane) instead of 2 x 128 B with one dword per lane -- 4x fewer store instructions
     // on the output-bound GEMMs (dz = g Wf^T writes 9*Cin floats per node).
-    __shared__ __attribute__((aligned(16))) float Es[4][32][36];
+    float (*Es)[32][36] = reinterpret_cast<float (*)[32][36]>(smem);     // the k loop ended on a barrier
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -482,6 +485,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
             const GemmEpilogue& ep, hipStream_t s) {
   if (M <= 0 || N <= 0) return 0;
   GEOBI_REQUIRE(K > 0, "gemm_nn: K must be positive");
+  prof_begin(PROF_GEMM, s, 2.0 * M * N * K, 1);          // "bytes" carries the flop count here
   dim3 block(256);
   const bool fast = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((K & 3) == 0) && K >= 4 &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && (transB || ((N & 3) == 0 && N >= 4));
@@ -547,6 +551,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
                                                                   ep.C1, ep.split, ep.ldc1);
     GEOBI_LAUNCH_OK();
   }
+  prof_end(PROF_GEMM, s);
   return 0;
 }
 
@@ -562,6 +567,7 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   Arena a(ws, ws_bytes);
   float* slabs = a.take<float>((size_t)p.blocks_y * I * J);
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  prof_begin(PROF_GEMM, s, 2.0 * (double)M * I * J, 2);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
 #define GEOBI_TN(TI_, TJ_)                                                                                  \
   gemm_tn_kernel<TI_, TJ_><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j,       \
@@ -578,6 +584,7 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   GEOBI_LAUNCH_OK();
   tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
   GEOBI_LAUNCH_OK();
+  prof_end(PROF_GEMM, s);
   return 0;
 }
 

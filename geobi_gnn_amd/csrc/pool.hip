@@ -438,42 +438,74 @@ __global__ void gather_f32_kernel(const float* __restrict__ src, const int* __re
 
 // Exclusive scan of up to a few hundred thousand ints in ONE launch (one 1024-thread block walking the
 // array with a running carry).  The graph levels of this path have <= ~10^5 nodes, where two rocPRIM
-// launches (init + lookback) cost more in launch latency than the scan itself.
+// launches (init + lookback) cost more in launch latency than the scan itself.  Each thread owns 16
+// consecutive ints per step (16 K per step for the block); the loads of the next step are issued before
+// the current one is scanned, the carry lives in a register and the wave sums are double-buffered, so
+// a step costs one barrier.
 __global__ __launch_bounds__(1024) void small_exclusive_scan_kernel(const int* __restrict__ in, int* __restrict__ out,
                                                                     int64_t n) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
+  constexpr int EPT = 16, CHUNK = 1024 * EPT;
+  __shared__ int wsum[2][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < n; base += 4096) {
-    // 4 consecutive elements per thread
-    const int64_t i0 = base + (int64_t)threadIdx.x * 4;
-    int v[4];
+  const bool vec = ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+  int cur[EPT], nxt[EPT];
+  auto load = [&](int64_t base, int* v) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+    if (vec && i0 + EPT <= n) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (i0 + q < n) ? in[i0 + q] : 0;
-    const int tsum = v[0] + v[1] + v[2] + v[3];
+      for (int q = 0; q < EPT / 4; ++q) {
+        int4 t = *reinterpret_cast<const int4*>(in + i0 + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) v[q] = (i0 + q < n) ? in[i0 + q] : 0;
+    }
+  };
+  int carry = 0, buf = 0;
+  load(0, cur);
+  for (int64_t base = 0; base < n; base += CHUNK, buf ^= 1) {
+    if (base + CHUNK < n) load(base + CHUNK, nxt);
+    int tsum = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) tsum += cur[q];
     int inc = tsum;                                   // inclusive scan of thread sums inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       int t = __shfl_up(inc, d, 64);
       if (lane >= d) inc += t;
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (lane == 63) wsum[buf][wave] = inc;
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    int total = 0;
-    for (int w = 0; w < 16; ++w) total += wsum[w];
-    int ex = carry_s + woff + inc - tsum;             // exclusive prefix of this thread's first element
+    int woff = 0, total = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (i0 + q < n) out[i0 + q] = ex;
-      ex += v[q];
+    for (int w = 0; w < 16; ++w) {
+      const int t = wsum[buf][w];
+      woff += w < wave ? t : 0;
+      total += t;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s += total;
-    __syncthreads();
+    int ex = carry + woff + inc - tsum;               // exclusive prefix of this thread's first element
+    carry += total;
+    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+    if (vec && i0 + EPT <= n) {
+#pragma unroll
+      for (int q = 0; q < EPT / 4; ++q) {
+        int4 t;
+        t.x = ex; ex += cur[4 * q];
+        t.y = ex; ex += cur[4 * q + 1];
+        t.z = ex; ex += cur[4 * q + 2];
+        t.w = ex; ex += cur[4 * q + 3];
+        *reinterpret_cast<int4*>(out + i0 + 4 * q) = t;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        if (i0 + q < n) out[i0 + q] = ex;
+        ex += cur[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) cur[q] = nxt[q];
   }
 }
 

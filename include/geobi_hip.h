@@ -216,9 +216,11 @@ int geobi_set_overlap(int enable);
 /* ---------------------------------------------------------------- measurement --------------
  * When enabled, the selected kernel family is bracketed with HIP events on its launch stream
  * (kernel: 1 = FeaSt aggregation forward, 2 = transposed aggregation backward, 3 = backward row
- * pass).  geobi_prof_collect synchronises the recorded events and returns the launch count, the
- * summed device time (ms) and the summed ALGORITHMIC bytes of launches whose
- * channel count equals `tag` (tag = 0: all).                                                     */
+ * pass, 4 = the dense GEMMs).  geobi_prof_collect synchronises the recorded events and returns the
+ * launch count, the summed device time (ms) and the summed ALGORITHMIC bytes
+ * of launches whose channel count equals `tag` (tag = 0: all).  For kernel 4 the third figure is the
+ * flop count 2*M*N*K instead and the tag is 1 for gemm_nn (+ its split-K reduce), 2 for gemm_tn
+ * (+ its slab reduce).                                                                            */
 int geobi_prof_enable(int kernel);
 int geobi_prof_collect(int tag, int64_t* launches, double* total_ms, double* total_bytes);
 
