@@ -279,17 +279,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slic
 // Each wave owns a (32*TI) x (32*TJ) output tile and a slice of the reduction (node) range.
 // Operands are read straight from global memory in MFMA fragment order: for a k-step of two
 // consecutive nodes, lanes 0-31 read 32 consecutive floats of node m, lanes 32-63 of node m+1.
-template <int TI, int TJ>
+// TN kernel.  Every load is unconditional from a clamped (always valid) address and nothing is selected
+// at load time, so the compiler can count the loads of the NEXT stage as outstanding (s_waitcnt vmcnt(n))
+// while the MFMAs of the current one run; masks (node tail, implicit ones row / column) are applied to the
+// registers right before the MFMAs.  Garbage in lanes whose column lies beyond I (or J) only reaches
+// accumulator rows (columns) that are never stored.
+//   VA: the lane loads A[m][i0 + 4 l .. + 3] as ONE 16-B load and MFMA tile a takes component a, i.e.
+//       tile a owns output rows i0 + 4 r + a (undone at the write-out).  Needs lda, the data column count
+//       and the base address to be multiples of 4 floats.  Otherwise tile a owns rows i0 + 32 a + r and
+//       loads one dword per tile.
+template <int TI, int TJ, int U, bool VA>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int64_t M, int I,
                                                       int J, int ones_row, int ones_col, int tiles_j,
                                                       int64_t m_per_slice, float* __restrict__ slabs) {
   // I, J are the LOGICAL output sizes; row `ones_row` of A^T / column `ones_col` of B read as 1
-  // (bias-style column sums ride along in the same pass); pass -1 to disable.
+  // (bias-style column sums ride along in the same pass); pass -1 to disable.  They are always the
+  // LAST logical row / column.
   // The 4 waves of a block own 4 consecutive node slices of the SAME output tile and fold their
   // accumulators through LDS, so one slab is written per block (4x fewer slabs to reduce).
+  static_assert(!VA || TI == 4, "vector A loads feed 4 row tiles");
   __shared__ float red[2][TI * TJ * 16 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: node rows stay in SGPRs
   const int tile = blockIdx.x;
   const int ti = tile / tiles_j, tj = tile % tiles_j;
   const int slice = blockIdx.y * 4 + wave;
@@ -297,6 +309,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   int64_t m_end = m_begin + m_per_slice;
   if (m_end > M) m_end = M;
   const int i0 = ti * 32 * TI, j0 = tj * 32 * TJ;
+  const int Id = I - (ones_row >= 0 ? 1 : 0), Jd = J - (ones_col >= 0 ? 1 : 0);   // columns that exist in memory
+  const int half = lane >> 5, l31 = lane & 31;
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -306,47 +320,98 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int half = lane >> 5, l31 = lane & 31;
-  float a0[4][TI], b0[4][TJ], a1[4][TI], b1[4][TJ];
+  // per-lane column offsets (clamped into the matrix) and the lanes that carry the implicit ones
+  int ia[VA ? 1 : TI], jb[TJ];
+  bool a_one[TI], b_one[TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a) {
+    const int ii = VA ? i0 + 4 * l31 + a : i0 + 32 * a + l31;
+    a_one[a] = ii == ones_row;
+    if (VA) { if (a == 0) ia[0] = min(ii, Id - 4); }
+    else ia[a] = min(ii, Id - 1);
+  }
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) {
+    const int jj = j0 + 32 * b + l31;
+    b_one[b] = jj == ones_col;
+    jb[b] = min(jj, Jd - 1);
+  }
+  const bool ones_a_here = ones_row >= i0 && ones_row < i0 + 32 * TI;     // wave-uniform
+  const bool ones_b_here = ones_col >= j0 && ones_col < j0 + 32 * TJ;
 
-  auto load8 = [&](float (&av)[4][TI], float (&bv)[4][TJ], int64_t m) {
+  float a0[U][TI], b0[U][TJ], a1[U][TI], b1[U][TJ];
+
+  // Addresses: the node row m + 2u is wave-uniform (scalar base pointer, clamped to the last row); the
+  // lane adds its column and, for the odd node of the pair, one row -- 32-bit offsets, ~1 VALU op per load.
+  const int half_lda = half ? lda : 0, half_ldb = half ? ldb : 0;
+  auto load = [&](float (&av)[U][TI], float (&bv)[U][TJ], int64_t m) {
+    const int64_t mb = m < M ? m : M - 1;                      // stage base row, 64-bit once per stage
+    const int64_t left = M - 1 - mb;
+    const int last = left > 4 * U ? 4 * U : (int)left;         // rows available past the base, 32-bit
+    const float* as = A + mb * lda;
+    const float* bs = B + mb * ldb;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int64_t mm = m + 2 * u + half;
-      bool ok = mm < m_end;
+    for (int u = 0; u < U; ++u) {
+      const int rel = 2 * u < last ? 2 * u : last;             // clamped to the last row
+      const bool odd_ok = 2 * u + 1 <= last;                   // uniform: the pair's odd node exists
+      const float* ap = as + rel * lda;
+      const float* bp = bs + rel * ldb;
+      const int da = odd_ok ? half_lda : 0, db = odd_ok ? half_ldb : 0;
+      if constexpr (VA) {
+        const float4 t = *reinterpret_cast<const float4*>(ap + (ia[0] + da));
+        av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w;
+      } else {
 #pragma unroll
-      for (int a = 0; a < TI; ++a) {
-        int ii = i0 + a * 32 + l31;
-        av[u][a] = (ok && ii < I) ? (ii == ones_row ? 1.0f : A[mm * lda + ii]) : 0.f;
+        for (int a = 0; a < TI; ++a) av[u][a] = ap[ia[a] + da];
       }
 #pragma unroll
-      for (int b = 0; b < TJ; ++b) {
-        int jj = j0 + b * 32 + l31;
-        bv[u][b] = (ok && jj < J) ? (jj == ones_col ? 1.0f : B[mm * ldb + jj]) : 0.f;
-      }
+      for (int b = 0; b < TJ; ++b) bv[u][b] = bp[jb[b] + db];
     }
   };
-  auto mma8 = [&](float (&av)[4][TI], float (&bv)[4][TJ]) {
+  auto mma = [&](float (&av)[U][TI], float (&bv)[U][TJ], int64_t m) {
+    const bool full = m + 2 * U <= m_end;                     // wave-uniform: no node mask needed
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u) {
+      float x[TI], y[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; ++a) x[a] = av[u][a];
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) y[b] = bv[u][b];
+      if (ones_a_here) {
+#pragma unroll
+        for (int a = 0; a < TI; ++a) x[a] = a_one[a] ? 1.0f : x[a];
+      }
+      if (ones_b_here) {
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) y[b] = b_one[b] ? 1.0f : y[b];
+      }
+      if (!full) {
+        const bool ok = m + 2 * u + half < m_end;
+#pragma unroll
+        for (int a = 0; a < TI; ++a) x[a] = ok ? x[a] : 0.f;
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) y[b] = ok ? y[b] : 0.f;
+      }
 #pragma unroll
       for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[a], y[b], acc[a][b], 0, 0, 0);
+    }
   };
 
-  // two register buffers: the loads of the next 8 nodes are in flight while 8 nodes multiply
-  load8(a0, b0, m_begin);
-  for (int64_t m = m_begin; m < m_end; m += 16) {
-    load8(a1, b1, m + 8);
-    mma8(a0, b0);
-    load8(a0, b0, m + 16);
-    mma8(a1, b1);
+  // two register stages of 2U nodes: the loads of the next stage are in flight while this one multiplies
+  if (m_begin < m_end) {
+    load(a0, b0, m_begin);
+    for (int64_t m = m_begin; m < m_end; m += 4 * U) {
+      load(a1, b1, m + 2 * U);
+      mma(a0, b0, m);
+      load(a0, b0, m + 4 * U);
+      if (m + 2 * U < m_end) mma(a1, b1, m + 2 * U);
+    }
   }
 
   // ---- fold the 4 waves: (2,3) -> LDS -> (0,1) add; 1 -> LDS -> 0 adds and writes the slab
-  constexpr int PER = TI * TJ * 16;
   if (wave >= 2) {
 #pragma unroll
     for (int a = 0; a < TI; ++a)
@@ -375,7 +440,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   }
   __syncthreads();
   if (wave != 0) return;
-  (void)PER;
   float* out = slabs + (size_t)blockIdx.y * I * J;
 #pragma unroll
   for (int a = 0; a < TI; ++a)
@@ -385,7 +449,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[a][b][r] + red[0][((a * TJ + b) * 16 + r) * 64 + lane];
-        int ii = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ii = VA ? i0 + 4 * rr + a : i0 + a * 32 + rr;
         if (jj < J && ii < I) out[(size_t)ii * J + jj] = v;
       }
     }
@@ -451,31 +516,41 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int block
 }
 
 struct TnPlan {
-  int ti, tj, tiles_i, tiles_j, slices, blocks_y;
+  int ti, tj, va, u, tiles_i, tiles_j, slices, blocks_y;
   int64_t m_per_slice;
 };
 
-TnPlan plan_tn(int I, int J, int64_t M) {
+TnPlan plan_tn(const float* A, int lda, int I, int J, int64_t M, int ones_row) {
   TnPlan p;
   // per-wave tile = (32 TI) x (32 TJ): as large as the shape fills (MFMA work is padded to tiles)
   int ci = cdiv(I, 32), cj = cdiv(J, 32);
-  p.ti = ci >= 2 ? 2 : 1;
-  p.tj = cj >= 4 ? 2 : cj;              // 1, 2 or 3 column tiles per wave; >= 4 -> pairs
+  const int Id = I - (ones_row >= 0 ? 1 : 0);
+  p.va = ci >= 3 && (lda & 3) == 0 && (Id & 3) == 0 && Id >= 4 && (((uintptr_t)A) & 15) == 0;
+  if (p.va) {
+    p.ti = 4;                           // one 16-B load feeds 4 row tiles; wider column tiles did not pay
+    p.tj = 1;                           // (1 wave/SIMD at 4x2 accumulators), see tools/tn_probe.hip
+  } else {
+    p.ti = ci >= 2 ? 2 : 1;
+    p.tj = cj >= 4 ? 2 : cj;            // 1, 2 or 3 column tiles per wave; >= 4 -> pairs
+  }
+  p.u = 4;
   p.tiles_i = cdiv(I, 32 * p.ti);
   p.tiles_j = cdiv(J, 32 * p.tj);
   int tiles = p.tiles_i * p.tiles_j;
-  int64_t want = 1536 / (tiles > 0 ? tiles : 1);     // target ~1.5k waves in flight (6 per CU)
-  // >= 256 nodes per slice; coarse levels (few nodes) are latency-bound per wave, so they get shorter
-  // slices (>= 64 nodes) and more waves instead
-  int64_t max_slices = (M <= 32768 || tiles <= 3) ? (M + 63) / 64 : (M + 255) / 256;
-  int64_t sl = want < 4 ? 4 : want;
-  if (sl > max_slices) sl = max_slices;
-  if (sl < 1) sl = 1;
-  sl = (sl + 3) / 4 * 4;                             // 4 waves (slices) per block
-  p.slices = (int)sl;
-  p.blocks_y = p.slices / 4;
-  int64_t mps = (M + sl - 1) / sl;
-  p.m_per_slice = (mps + 15) / 16 * 16;
+  // About two blocks per CU in ONE resident round (a second, partial round would idle most CUs for a
+  // whole block time; more, shorter slices only add slab traffic), each wave taking >= 64 nodes.
+  const int64_t capacity = 512;
+  int64_t by = capacity / (tiles > 0 ? tiles : 1);
+  if (by < 1) by = 1;
+  int64_t max_by = (M + 255) / 256;                  // 4 waves x 64 nodes per block at least
+  if (by > max_by) by = max_by;
+  if (by < 1) by = 1;
+  const int stage = 2 * p.u;
+  int64_t mps = (M + 4 * by - 1) / (4 * by);
+  p.m_per_slice = (mps + stage - 1) / stage * stage;  // whole stages
+  p.blocks_y = (int)((M + 4 * p.m_per_slice - 1) / (4 * p.m_per_slice));
+  if (p.blocks_y < 1) p.blocks_y = 1;
+  p.slices = 4 * p.blocks_y;
   return p;
 }
 
@@ -512,7 +587,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
                              ? (int64_t)cdiv(M, 64) * cdiv(N, 64) : (int64_t)cdiv(M, 32) * cdiv(N, 128);
   if (ep.fixed_slices > 0) {
     if (ep.fixed_slices > 1 && ep.ws != nullptr) {
-      k_chunk = ((K + ep.fixed_slices - 1) / ep.fixed_slices + 31) / 32 * 32;
+      k_chunk = ((K + ep.fixed_slices - 1) / ep.fixed_slices + 63) / 64 * 64;
       slices = (K + k_chunk - 1) / k_chunk;
       if (slices > 1 && (size_t)slices * M * N * sizeof(float) <= ep.ws_bytes) partial = (float*)ep.ws;
       else { slices = 1; k_chunk = K; }
@@ -523,7 +598,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
     slices = want < maxs ? want : maxs;
     if (slices > 8) slices = 8;
     if (slices < 1) slices = 1;
-    k_chunk = ((K + slices - 1) / slices + 31) / 32 * 32;       // whole k-tiles per slice
+    k_chunk = ((K + slices - 1) / slices + 63) / 64 * 64;       // whole k-tiles per slice
     slices = (K + k_chunk - 1) / k_chunk;
     if (slices > 1 && (size_t)slices * M * N * sizeof(float) <= ep.ws_bytes) partial = (float*)ep.ws;
     else { slices = 1; k_chunk = K; }
@@ -531,17 +606,22 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   // 16-B row stores need a plain, aligned, 4-float-granular output
   const int wide = (partial == nullptr && ep.C1 == nullptr && (ldc & 3) == 0 && (N & 3) == 0 &&
                     (((uintptr_t)C) & 15) == 0 && (ep.bias == nullptr || (((uintptr_t)ep.bias) & 15) == 0)) ? 1 : 0;
+  // one-tile-per-wave shapes: 64-deep k-tiles when there is k to cover (half the barriers per MFMA and
+  // twice the prefetch distance)
+  const bool deep = k_chunk >= 128;
   if (big_blocks >= 384) {
     if (N > 64)
       GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
     else if (N > 32)
       GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32);  // 128 x 64
+    else if (deep)
+      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 64);  // 128 x 32
     else
-      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);  // 128 x 32
+      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);
   } else if (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256) {
-    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);    // 64 x 64
+    if (deep) GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 64); else GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);    // 64 x 64
   } else {
-    GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 32);    // 32 x 128
+    if (deep) GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 64); else GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 32);    // 32 x 128
   }
 #undef GEOBI_GEMM_LAUNCH
 #undef GEOBI_GEMM_LAUNCH_F
@@ -556,29 +636,41 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
 }
 
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
-  TnPlan p = plan_tn(I, J, M);
-  return align_up((size_t)p.blocks_y * I * J * sizeof(float)) + 256;
+  // the slab count depends on the tile shape, which depends on the alignment of A: take the larger
+  TnPlan p0 = plan_tn(nullptr, 4, I, J, M, (I & 3) == 1 ? I - 1 : -1);
+  TnPlan p1 = plan_tn(nullptr, 1, I, J, M, -1);
+  int by = p0.blocks_y > p1.blocks_y ? p0.blocks_y : p1.blocks_y;
+  return align_up((size_t)by * I * J * sizeof(float)) + 256;
 }
 
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
             const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s) {
   if (I <= 0 || J <= 0) return 0;
-  TnPlan p = plan_tn(I, J, M);
+  GEOBI_REQUIRE(M >= 0 && I - (ones_row >= 0) >= 1 && J - (ones_col >= 0) >= 1, "gemm_tn: empty operand");
+  GEOBI_REQUIRE(ones_row < 0 || ones_row == I - 1, "gemm_tn: the ones row is the last row");
+  GEOBI_REQUIRE(ones_col < 0 || ones_col == J - 1, "gemm_tn: the ones column is the last column");
+  TnPlan p = plan_tn(A, lda, I, J, M, ones_row);
   Arena a(ws, ws_bytes);
   float* slabs = a.take<float>((size_t)p.blocks_y * I * J);
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
   prof_begin(PROF_GEMM, s, 2.0 * (double)M * I * J, 2);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
-#define GEOBI_TN(TI_, TJ_)                                                                                  \
-  gemm_tn_kernel<TI_, TJ_><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col, p.tiles_j,       \
-                                                 p.m_per_slice, slabs)
-  switch (p.ti * 10 + p.tj) {
-    case 11: GEOBI_TN(1, 1); break;
-    case 12: GEOBI_TN(1, 2); break;
-    case 13: GEOBI_TN(1, 3); break;
-    case 21: GEOBI_TN(2, 1); break;
-    case 22: GEOBI_TN(2, 2); break;
-    default: GEOBI_TN(2, 3); break;
+  if (M == 0) {                                     // no nodes: the sums are zero
+    GEOBI_HIP(hipMemsetAsync(slabs, 0, (size_t)p.blocks_y * I * J * sizeof(float), s));
+    p.va = 9;                                       // no kernel below
+  }
+#define GEOBI_TN(TI_, TJ_, U_, VA_)                                                                         \
+  gemm_tn_kernel<TI_, TJ_, U_, VA_><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col,         \
+                                                          p.tiles_j, p.m_per_slice, slabs)
+  switch (p.va * 100 + p.ti * 10 + p.tj) {
+    case 900 ... 999: break;
+    case 141: GEOBI_TN(4, 1, 4, true); break;
+    case 11: GEOBI_TN(1, 1, 4, false); break;
+    case 12: GEOBI_TN(1, 2, 4, false); break;
+    case 13: GEOBI_TN(1, 3, 4, false); break;
+    case 21: GEOBI_TN(2, 1, 4, false); break;
+    case 22: GEOBI_TN(2, 2, 4, false); break;
+    default: GEOBI_TN(2, 3, 4, false); break;
   }
 #undef GEOBI_TN
   GEOBI_LAUNCH_OK();

@@ -32,6 +32,10 @@ def tn(M, I, J):
     print('TN  M=%6d I=%5d J=%5d       %8.1f us  %6.1f TF/s  %6.0f GB/s' % (M, I, J, us, 2.0 * M * I * J / us / 1e6, gb / us * 1e6))
 
 N0, N1, N2 = 81920, 22000, 6000
+ONLY_TN = len(sys.argv) > 1 and sys.argv[1] == 'tn'
+_nn = nn
+if ONLY_TN:
+    nn = lambda *a, **k: None
 print('--- forward out = z Wf')
 for M, N, K in [(N0, 32, 108), (N0, 32, 576), (N1, 64, 288), (N1, 64, 1152), (N2, 128, 576), (N2, 128, 1152)]: nn(M, N, K)
 print('--- backward dz = g Wf^T')
@@ -41,6 +45,6 @@ for M, N, K in [(N0, 64, 312), (N0, 12, 312), (N1, 128, 600), (N1, 32, 600), (N2
 print('--- heads')
 nn(N0, 1024, 32, 1); nn(N0, 32, 1024)
 print('--- weight gradients')
-for M, I, J in [(N0, 577, 32), (N0, 109, 32), (N1, 1153, 64), (N1, 289, 64), (N2, 577, 128), (N2, 1153, 128),
+for M, I, J in [(N0, 576, 32), (N0, 108, 32), (N1, 1152, 64), (N1, 288, 64), (N2, 576, 128), (N2, 1152, 128),   # z^T g (the model adds an implicit ones row)
                 (N0, 24, 65), (N0, 24, 33), (N0, 24, 13), (N1, 24, 129), (N1, 24, 33), (N2, 24, 65), (N2, 24, 129),
                 (N0, 3, 1025), (N0, 1024, 33)]: tn(M, I, J)
