@@ -301,6 +301,55 @@ int geobi_update_position2(const float* points, const int32_t* fv, const int32_t
   return update_position2(points, fv, vf, maxval, normals, dd, V, F, n_iter, out, ws, ws_bytes, S(stream));
 }
 
+size_t geobi_vertex_faces_ws_bytes(int64_t F, int64_t V) { return vertex_faces_ws_bytes(F, V); }
+
+int geobi_vertex_faces(const int32_t* fv, int64_t F, int64_t V, int32_t* rowptr, int32_t* list, void* ws,
+                       size_t ws_bytes, void* stream) {
+  NOTNULL(fv); NOTNULL(rowptr); NOTNULL(list); NOTNULL(ws);
+  return vertex_faces(fv, F, V, rowptr, list, ws, ws_bytes, S(stream));
+}
+
+int geobi_vf_padded(const int32_t* rowptr, const int32_t* list, int64_t V, int maxval, int32_t* vf, void* stream) {
+  NOTNULL(rowptr); NOTNULL(list); NOTNULL(vf);
+  return vf_padded(rowptr, list, V, maxval, vf, S(stream));
+}
+
+int geobi_max_degree(const int32_t* rowptr, int64_t N, int32_t* out, void* stream) {
+  NOTNULL(rowptr); NOTNULL(out);
+  return max_degree(rowptr, N, out, S(stream));
+}
+
+int geobi_mesh_normals(const float* points, const int32_t* fv, int64_t F, int64_t V, const int32_t* rowptr,
+                       const int32_t* list, float* fnormal, float* centroid, float* vnormal, void* stream) {
+  NOTNULL(points); NOTNULL(fv); NOTNULL(fnormal); NOTNULL(centroid);
+  if (vnormal != nullptr) { NOTNULL(rowptr); NOTNULL(list); }
+  return mesh_normals(points, fv, F, V, rowptr, list, fnormal, centroid, vnormal, S(stream));
+}
+
+size_t geobi_ring_graph_ws_bytes(int64_t n_nodes) { return ring_graph_ws_bytes(n_nodes); }
+
+int geobi_ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
+                           int64_t n_nodes, int32_t* rowptr_g, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(fv); NOTNULL(rowptr_vf); NOTNULL(list); NOTNULL(rowptr_g); NOTNULL(ws);
+  return ring_graph_count(kind, fv, rowptr_vf, list, n_nodes, rowptr_g, ws, ws_bytes, S(stream));
+}
+
+int geobi_ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
+                          int64_t n_nodes, const int32_t* rowptr_g, int32_t* col, void* stream) {
+  NOTNULL(fv); NOTNULL(rowptr_vf); NOTNULL(list); NOTNULL(rowptr_g); NOTNULL(col);
+  return ring_graph_fill(kind, fv, rowptr_vf, list, n_nodes, rowptr_g, col, S(stream));
+}
+
+size_t geobi_calc_weight_ws_bytes(void) { return calc_weight_ws_bytes(); }
+
+int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
+                      int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(pos); NOTNULL(ws);
+  if (E > 0) { NOTNULL(row); NOTNULL(col); }
+  if (w != nullptr) NOTNULL(normal);
+  return calc_weight(pos, normal, row, col, E, extra_zero_edges, w, mean_len, ws, ws_bytes, S(stream));
+}
+
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
                   int K, const float* bias, float slope, void* stream) {
   NOTNULL(A); NOTNULL(B); NOTNULL(C);

@@ -161,6 +161,25 @@ size_t pool_edge_ws_bytes(int64_t E);
 int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E, int64_t nmax,
               int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, void* ws,
               size_t ws_bytes, hipStream_t s);
+// meshprep.hip (mesh -> graphs / normals / bilateral weights on the device)
+size_t vertex_faces_ws_bytes(int64_t F, int64_t V);
+int vertex_faces(const int32_t* fv, int64_t F, int64_t V, int32_t* rowptr, int32_t* list, void* ws, size_t ws_bytes,
+                 hipStream_t s);
+int vf_padded(const int32_t* rowptr, const int32_t* list, int64_t V, int maxval, int32_t* vf, hipStream_t s);
+int max_degree(const int32_t* rowptr, int64_t N, int32_t* out, hipStream_t s);
+int mesh_normals(const float* points, const int32_t* fv, int64_t F, int64_t V, const int32_t* rowptr,
+                 const int32_t* list, float* fnormal, float* centroid, float* vnormal, hipStream_t s);
+size_t ring_graph_ws_bytes(int64_t n_nodes);
+int ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list, int64_t n_nodes,
+                     int32_t* rowptr_g, void* ws, size_t ws_bytes, hipStream_t s);
+int ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list, int64_t n_nodes,
+                    const int32_t* rowptr_g, int32_t* col, hipStream_t s);
+size_t calc_weight_ws_bytes();
+int calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
+                int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, hipStream_t s);
+// pool.hip: exclusive int scan shared with meshprep.hip (single launch below 2^18 elements)
+size_t scan_ws_bytes(int64_t n);
+int scan_exclusive_i32(void* temp, size_t temp_bytes, const int* in, int* out, int64_t n, hipStream_t s);
 // geom.hip
 int face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
                   hipStream_t s);

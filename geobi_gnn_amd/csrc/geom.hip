@@ -381,8 +381,6 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
   size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
   size_t tnb = t1 > t2 ? t1 : t2;
   void* tn_ws = a.take<char>(tnb);
-  size_t csb = colsum_ws_bytes(N, K);
-  void* cs_ws = a.take<char>(csb);
   GEOBI_REQUIRE(a.ok() && ws, "head_bwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
   head_finish_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(gout, raw, nout, mode, dd, (int)N, graw);
   GEOBI_LAUNCH_OK();

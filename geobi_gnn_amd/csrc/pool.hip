@@ -544,6 +544,17 @@ size_t sort_pairs_temp_bytes(int64_t n) {
 
 }  // namespace
 
+size_t scan_ws_bytes(int64_t n) {
+  size_t tb = n <= kSmallScan ? 16 : scan_temp_bytes<int>(n);
+  return align_up(tb ? tb : 16);
+}
+
+int scan_exclusive_i32(void* temp, size_t temp_bytes, const int* in, int* out, int64_t n, hipStream_t s) {
+  size_t tb = temp_bytes;
+  GEOBI_HIP(exclusive_scan_int(temp, tb, in, out, n, s));
+  return 0;
+}
+
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
                     float* w_out, hipStream_t s) {
   if (E <= 0) return 0;

@@ -199,6 +199,43 @@ int geobi_update_position2(const float* points, const int32_t* fv, const int32_t
                            const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- mesh -> graphs ----
+ * What the reference's loader computes on the CPU with openmesh / PyG before the network runs
+ * (code/dataset.py:197-233 process_one_submesh).  fv = face->vertex table [F,3] int32.
+ *   geobi_vertex_faces   vertex->face incidence as CSR (rowptr [V+1], list [3F], face ids ascending):
+ *                        openmesh vf_indices (dataset.py:203); geobi_vf_padded emits the [V, maxval]
+ *                        -1 padded table update_position2 takes; geobi_max_degree -> maxval (device int).
+ *   geobi_mesh_normals   unit face normals + face centroids (dataset.py:222-224) and vertex normals =
+ *                        normalised sum of incident face normals (openmesh update_vertex_normals,
+ *                        dataset.py:198-199); fp64 inside, fp32 out.  vnormal may be NULL.
+ *   geobi_ring_graph_*   kind 0: vertex graph = mesh edges in both directions (to_undirected(ev.T),
+ *                        dataset.py:211-212); kind 1: facet graph = faces sharing >= 1 vertex
+ *                        (data_util.build_facet_graph, code/data_util.py:436-456).  Output is the
+ *                        (row, col)-sorted CSR WITHOUT self loops that the conv / pooling entry points
+ *                        take (the reference appends / inlines one loop per node; FeaStConv and the
+ *                        pooling layer drop them again).  _count writes rowptr_g [n+1] (read
+ *                        rowptr_g[n] = E to size col), _fill writes col [E].
+ *   geobi_calc_weight    data_util.calc_weight (code/data_util.py:383-398) over the loop-free edges:
+ *                        clamp(n_i.n_j, 1e-3) * exp(|p_i-p_j|^2 / (-2 mean|p_i-p_j| + 1e-12)); the mean
+ *                        runs over E + extra_zero_edges entries (the reference's edge list carries one
+ *                        zero-length self loop per node).  w may be NULL; mean_len (device float,
+ *                        optional) receives the mean -- center_and_scale's 1/scale (data_util.py:201-230). */
+size_t geobi_vertex_faces_ws_bytes(int64_t F, int64_t V);
+int geobi_vertex_faces(const int32_t* fv, int64_t F, int64_t V, int32_t* rowptr, int32_t* list, void* ws,
+                       size_t ws_bytes, void* stream);
+int geobi_vf_padded(const int32_t* rowptr, const int32_t* list, int64_t V, int maxval, int32_t* vf, void* stream);
+int geobi_max_degree(const int32_t* rowptr, int64_t N, int32_t* out, void* stream);
+int geobi_mesh_normals(const float* points, const int32_t* fv, int64_t F, int64_t V, const int32_t* rowptr,
+                       const int32_t* list, float* fnormal, float* centroid, float* vnormal, void* stream);
+size_t geobi_ring_graph_ws_bytes(int64_t n_nodes);
+int geobi_ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
+                           int64_t n_nodes, int32_t* rowptr_g, void* ws, size_t ws_bytes, void* stream);
+int geobi_ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
+                          int64_t n_nodes, const int32_t* rowptr_g, int32_t* col, void* stream);
+size_t geobi_calc_weight_ws_bytes(void);
+int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
+                      int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- dense helpers ------------
  * Plain fp32 MFMA GEMMs used by the layers above, exported for tests and profiling.            */
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
