@@ -350,6 +350,32 @@ int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row,
   return calc_weight(pos, normal, row, col, E, extra_zero_edges, w, mean_len, ws, ws_bytes, S(stream));
 }
 
+int geobi_patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F,
+                          int64_t seed, int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n) {
+  NOTNULL(fv); NOTNULL(vf_rowptr); NOTNULL(vf_list); NOTNULL(out); NOTNULL(out_n);
+  return patch_grow_host(fv, vf_rowptr, vf_list, F, seed, neighbor_count, ring_count, out, out_n);
+}
+
+size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V) { return submesh_ws_bytes(n_sel, V); }
+
+int geobi_submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
+                  int32_t* count, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(fv); NOTNULL(sel); NOTNULL(v_idx); NOTNULL(f_sub); NOTNULL(count); NOTNULL(ws);
+  return submesh(fv, sel, n_sel, V, v_idx, f_sub, count, ws, ws_bytes, S(stream));
+}
+
+int geobi_patch_accumulate(const float* vert_p, const float* norm_p, const int32_t* v_idx, const int32_t* f_idx,
+                           int64_t nv, int64_t nf, float* Vp, float* Np, int32_t* sum_v, void* stream) {
+  NOTNULL(vert_p); NOTNULL(norm_p); NOTNULL(v_idx); NOTNULL(f_idx); NOTNULL(Vp); NOTNULL(Np); NOTNULL(sum_v);
+  return patch_accumulate(vert_p, norm_p, v_idx, f_idx, nv, nf, Vp, Np, sum_v, S(stream));
+}
+
+int geobi_patch_finalize(float* Vp, float* Np, const int32_t* sum_v, int64_t V, int64_t F, float scale, float cx,
+                         float cy, float cz, void* stream) {
+  NOTNULL(Vp); NOTNULL(Np); NOTNULL(sum_v);
+  return patch_finalize(Vp, Np, sum_v, V, F, scale, cx, cy, cz, S(stream));
+}
+
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,
                   int K, const float* bias, float slope, void* stream) {
   NOTNULL(A); NOTNULL(B); NOTNULL(C);

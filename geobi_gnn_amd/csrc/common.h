@@ -177,6 +177,16 @@ int ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const
 size_t calc_weight_ws_bytes();
 int calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                 int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, hipStream_t s);
+// patch.hip (patch split / merge for large meshes)
+int patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F, int64_t seed,
+                    int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n);
+size_t submesh_ws_bytes(int64_t n_sel, int64_t V);
+int submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
+            int32_t* count, void* ws, size_t ws_bytes, hipStream_t s);
+int patch_accumulate(const float* vert_p, const float* norm_p, const int32_t* v_idx, const int32_t* f_idx, int64_t nv,
+                     int64_t nf, float* Vp, float* Np, int32_t* sum_v, hipStream_t s);
+int patch_finalize(float* Vp, float* Np, const int32_t* sum_v, int64_t V, int64_t F, float scale, float cx, float cy,
+                   float cz, hipStream_t s);
 // pool.hip: exclusive int scan shared with meshprep.hip (single launch below 2^18 elements)
 size_t scan_ws_bytes(int64_t n);
 int scan_exclusive_i32(void* temp, size_t temp_bytes, const int* in, int* out, int64_t n, hipStream_t s);

@@ -122,9 +122,11 @@ def _reference_coo(graph, weight, normal, loops_inline):
 
 
 def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type='Synthetic', device=None,
-                    reference_layout=False):
+                    reference_layout=False, centroid=None, scale=None):
     """(points [V,3], faces [F,3]) -> (data_v, data_f) as process_one_submesh + post_processing emit them,
-    computed on the device.  Same fields as ``meshgen.build_dual_data`` (incl. ``data_v.meta``)."""
+    computed on the device.  Same fields as ``meshgen.build_dual_data`` (incl. ``data_v.meta``).
+    ``centroid`` [1,3] / ``scale``: normalisation of the WHOLE mesh when this is one patch of it
+    (dataset.py:177-178 overwrite the patch's own values)."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     if not torch.cuda.is_available():
         raise L.GeobiError('meshprep.build_dual_data runs on the MI355X only (no CPU fallback); '
@@ -142,9 +144,11 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
     g_f = ring_graph(1, fv, rowptr_vf, lst, F)
 
     # center_and_scale, s_type 0: centroid = mean vertex, scale = 1 / mean mesh-edge length
-    cen = pts.mean(0, keepdim=True)
-    scale_t = 1.0 / mean_edge_length(pts, g_v)
-    sc = float(scale_t.item())
+    if centroid is None:
+        cen = pts.mean(0, keepdim=True)
+    else:
+        cen = torch.as_tensor(centroid, dtype=torch.float32).reshape(1, 3).to(dev)
+    sc = float((1.0 / mean_edge_length(pts, g_v)).item()) if scale is None else float(scale)
 
     ew_v = calc_weight(pts, vn, g_v)
     ew_f = calc_weight(pos_f, fn, g_f)

@@ -1,0 +1,118 @@
+"""Patch split / merge for meshes larger than one network pass.
+
+* split  /root/reference/code/dataset.py:156-193 (``process_one_data``: seed = face farthest from the
+         centroid, grow ``submesh_size`` faces ring by ring, next seed = farthest unvisited face) with
+         /root/reference/code/data_util.py:55-84 ``mesh_get_neighbor_np`` and :318-336 ``get_submesh``
+* merge  /root/reference/code/test_dual.py:49-61 (sum overlapping predictions, divide by the visit count,
+         re-normalise the normals) followed by the 60-sweep vertex update (:63-72)
+
+The ordered ring growth runs on the host (C++, ``geobi_patch_grow_host``); vertex renumbering, graph
+construction, the network and the merge run on the device.  The reference walks openmesh's ``vf_indices``
+rows; here the incidence lists are in ascending face order, so which faces the LAST, partial ring of a
+patch contributes can differ from an openmesh run (whole rings do not depend on the order).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import meshprep, network
+from .data_util import computer_face_normal, update_position2
+from .infer import predict_one_submesh
+
+
+def patch_grow(fv_host, rowptr_host, list_host, seed, neighbor_count=None, ring_count=None):
+    """data_util.mesh_get_neighbor_np on host arrays (int32, C-contiguous) -> face ids in visiting order."""
+    F = fv_host.shape[0]
+    out = np.empty(F, dtype=np.int32)
+    n = ctypes.c_int64(0)
+    L.call('geobi_patch_grow_host', fv_host.ctypes.data, rowptr_host.ctypes.data, list_host.ctypes.data, F, int(seed),
+           int(neighbor_count or 0), int(ring_count or 0), out.ctypes.data, ctypes.byref(n))
+    return out[:n.value]
+
+
+def submesh(fv, sel, num_vertices):
+    """data_util.get_submesh on the device: sel [n] int32 face ids -> (V_idx [nv] int32, F_sub [n,3] int32)."""
+    dev = fv.device
+    n, V = int(sel.shape[0]), int(num_vertices)
+    v_idx = torch.empty(min(V, 3 * n), dtype=torch.int32, device=dev)
+    f_sub = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = L.workspace(L.size_query('geobi_submesh_ws_bytes', n, V), dev)
+    L.call('geobi_submesh', L.ptr(fv), L.ptr(sel), n, V, L.ptr(v_idx), L.ptr(f_sub), L.ptr(count), L.ptr(ws),
+           ws.numel(), L.stream())
+    return v_idx[:int(count.item())], f_sub
+
+
+def split_patches(points, fv, submesh_size, incidence=None):
+    """Generator over the patches of dataset.py:156-193: yields (select_faces, V_idx, F_sub) device int32
+    tensors.  points [V,3] fp32 and fv [F,3] int32 live on the device."""
+    V, F = points.shape[0], fv.shape[0]
+    rowptr, lst = incidence if incidence is not None else meshprep.vertex_faces(fv, V)
+    fv_h = fv.cpu().numpy()
+    rp_h, ls_h = rowptr.cpu().numpy(), lst.cpu().numpy()
+    centroid = points.mean(0, keepdim=True)
+    face_cent = points[fv.long()].mean(1)
+    d2 = ((face_cent - centroid) ** 2).sum(1).cpu().numpy()
+    flag = np.zeros(F, dtype=bool)
+    seed = int(np.argmax(d2))
+    while True:
+        sel_h = patch_grow(fv_h, rp_h, ls_h, seed, neighbor_count=submesh_size)
+        flag[sel_h] = True
+        sel = torch.from_numpy(sel_h).to(fv.device)
+        v_idx, f_sub = submesh(fv, sel, V)
+        yield sel, v_idx, f_sub
+        left = np.where(~flag)[0]
+        if left.size == 0:
+            break
+        seed = int(left[np.argmax(d2[left])])
+
+
+def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None):
+    """test_dual.py:24-87 without the OBJ IO, for a mesh of any size: preprocessing, patch split when
+    F > sub_size, network, merge, de-normalisation, vertex update -- all device-resident.
+
+    Returns dict(Vp, Np, V_updated, n_patches, angle1, angle2)."""
+    dev = next(net.parameters()).device
+    pts = torch.as_tensor(np.asarray(points) if not torch.is_tensor(points) else points)
+    pts = pts.to(device=dev, dtype=torch.float32).contiguous()
+    fv = torch.as_tensor(np.asarray(faces) if not torch.is_tensor(faces) else faces).to(device=dev, dtype=torch.int32)
+    fv = fv.contiguous()
+    V, F = pts.shape[0], fv.shape[0]
+    rowptr, lst = meshprep.vertex_faces(fv, V)
+    g_v = meshprep.ring_graph(0, fv, rowptr, lst, V)
+    centroid = pts.mean(0, keepdim=True)
+    scale = float((1.0 / meshprep.mean_edge_length(pts, g_v)).item())
+
+    if F <= sub_size:
+        dual = meshprep.build_dual_data(pts, fv, name='mesh', data_type=data_type, device=dev)
+        Vp, Np = predict_one_submesh(net, dual)
+        Vp = Vp / scale + centroid
+        n_patches = 1
+    else:
+        Vp = torch.zeros((V, 3), dtype=torch.float32, device=dev)
+        Np = torch.zeros((F, 3), dtype=torch.float32, device=dev)
+        sum_v = torch.zeros(V, dtype=torch.int32, device=dev)
+        n_patches = 0
+        for sel, v_idx, f_sub in split_patches(pts, fv, sub_size, incidence=(rowptr, lst)):
+            dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, name='patch%d' % n_patches, data_type=data_type,
+                                            device=dev, centroid=centroid, scale=scale)
+            vert_p, norm_p = predict_one_submesh(net, dual)
+            L.call('geobi_patch_accumulate', L.ptr(vert_p.contiguous()), L.ptr(norm_p.contiguous()), L.ptr(v_idx),
+                   L.ptr(sel), v_idx.shape[0], sel.shape[0], L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), L.stream())
+            n_patches += 1
+        c = centroid.reshape(-1).tolist()
+        L.call('geobi_patch_finalize', L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), V, F, scale, c[0], c[1], c[2], L.stream())
+
+    dd = torch.nn.functional.normalize(pts, dim=1) if data_type in ('Kinect_v1', 'Kinect_v2') else None
+    vf = meshprep.vf_padded(rowptr, lst, V)
+    Vu = update_position2(Vp, fv, vf, Np, n_iter=n_iter, depth_direction=dd)
+    out = {'Vp': Vp, 'Np': Np, 'V_updated': Vu, 'n_patches': n_patches, 'angle1': None, 'angle2': None}
+    if gt_points is not None:
+        gt = torch.as_tensor(np.asarray(gt_points) if not torch.is_tensor(gt_points) else gt_points)
+        gt = gt.to(device=dev, dtype=torch.float32).contiguous()
+        Nt = computer_face_normal(gt, fv)
+        out['angle1'] = float(network.error_n(Np, Nt))
+        out['angle2'] = float(network.error_n(computer_face_normal(Vu, fv), Nt))
+    return out

@@ -236,6 +236,30 @@ size_t geobi_calc_weight_ws_bytes(void);
 int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                       int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- patch split / merge ----
+ * Meshes with more faces than one pass takes are cut into overlapping patches, denoised patch by patch
+ * and merged (code/dataset.py:156-193, code/test_dual.py:49-61).
+ *   geobi_patch_grow_host  HOST function over HOST arrays (the only one in this header): face-ring growth
+ *                          from `seed` until neighbor_count faces (<= 0: unlimited) or ring_count rings
+ *                          (<= 0: unlimited) are collected, in the visiting order of
+ *                          data_util.mesh_get_neighbor_np (code/data_util.py:55-84); vf as CSR, walked in
+ *                          list order.  out has room for min(neighbor_count, F) + a ring's overshoot = F ids.
+ *   geobi_submesh          data_util.get_submesh (code/data_util.py:318-336) on the device: sel [n_sel]
+ *                          face ids -> v_idx (original vertex ids in first-use order; capacity
+ *                          min(V, 3 n_sel)), f_sub [n_sel,3] renumbered faces, count (device int) = number
+ *                          of patch vertices.
+ *   geobi_patch_accumulate Vp[v_idx] += vert_p, sum_v[v_idx] += 1, Np[f_idx] += norm_p
+ *   geobi_patch_finalize   Vp = Vp / sum_v / scale + centroid; Np = normalize(Np) (eps 1e-12)            */
+int geobi_patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F,
+                          int64_t seed, int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n);
+size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V);
+int geobi_submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
+                  int32_t* count, void* ws, size_t ws_bytes, void* stream);
+int geobi_patch_accumulate(const float* vert_p, const float* norm_p, const int32_t* v_idx, const int32_t* f_idx,
+                           int64_t nv, int64_t nf, float* Vp, float* Np, int32_t* sum_v, void* stream);
+int geobi_patch_finalize(float* Vp, float* Np, const int32_t* sum_v, int64_t V, int64_t F, float scale, float cx,
+                         float cy, float cz, void* stream);
+
 /* ---------------------------------------------------------------- dense helpers ------------
  * Plain fp32 MFMA GEMMs used by the layers above, exported for tests and profiling.            */
 int geobi_gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N,

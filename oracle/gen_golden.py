@@ -165,12 +165,47 @@ def gen_pure_functions():
     print('wrote pure_functions.npz')
 
 
+def gen_patches():
+    """Patch split of dataset.py:156-193 on a small mesh: the loop is restated here (it lives inside
+    process_one_data, which reads OBJ files through openmesh), the two functions that do the work --
+    data_util.mesh_get_neighbor_np and data_util.get_submesh -- are the reference's own, called unmodified.
+    vf rows are in ascending face order (meshgen.vertex_faces), not openmesh's circulation order."""
+    from geobi_gnn_amd import meshgen
+    _, _, ref_data_util = _import_reference()
+    noisy, clean, faces = meshgen.noisy_icosphere(8, 0.2, seed=11)
+    fv = faces.astype(np.int64)
+    vf = meshgen.vertex_faces(faces, noisy.shape[0])
+    sub = 400
+    centroid = np.mean(noisy, axis=0, keepdims=True)
+    face_cent = noisy[fv].mean(1)
+    flag = np.zeros(fv.shape[0], dtype=bool)
+    seed = np.argmax(((face_cent - centroid) ** 2).sum(1))
+    sel_all, vidx_all, fsub_all, sizes, seeds = [], [], [], [], []
+    while True:
+        sel = np.asarray(ref_data_util.mesh_get_neighbor_np(fv, vf, seed, neighbor_count=sub))
+        flag.put(sel, True)
+        V_idx, Fs = ref_data_util.get_submesh(fv, sel)
+        seeds.append(int(seed)); sizes.append((len(sel), len(V_idx)))
+        sel_all.append(sel.astype(np.int32)); vidx_all.append(V_idx.astype(np.int32)); fsub_all.append(Fs.astype(np.int32))
+        left = np.where(~flag)[0]
+        if not left.size:
+            break
+        seed = left[np.argmax(((face_cent[left] - centroid) ** 2).sum(1))]
+    ring2 = np.asarray(ref_data_util.mesh_get_neighbor_np(fv, vf, 5, ring_count=2)).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, 'patches_n8.npz'), points=noisy, clean=clean, faces=faces.astype(np.int32),
+                        sub_size=np.int64(sub), seeds=np.array(seeds, dtype=np.int64),
+                        sizes=np.array(sizes, dtype=np.int64), select_faces=np.concatenate(sel_all),
+                        v_idx=np.concatenate(vidx_all), f_sub=np.concatenate(fsub_all, 0), ring2_from_face5=ring2)
+    print('wrote patches_n8.npz', len(seeds), 'patches', sizes)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     # one thread: multi-threaded CPU scatter/index_add backward is not run-to-run deterministic
     # (measured: the reference differs from ITSELF by ~1e-7 relative in the gradients at 4 threads)
     torch.set_num_threads(1)
     gen_pure_functions()
+    gen_patches()
     gen_dualgnn(4, mesh_seed=0, weight_seed=0)
     gen_dualgnn(11, mesh_seed=1, weight_seed=1)
     gen_dualgnn(4, mesh_seed=2, weight_seed=2, force_depth=True)

@@ -244,3 +244,27 @@ def test_op_tape_matches_autograd_on_a_dag():
     with ops.use_tape(tape):
         assert ops._ACTIVE_TAPE[0] is tape
     assert ops._ACTIVE_TAPE[0] is None
+
+
+def test_patch_growth_matches_reference_fixture():
+    """geobi_patch_grow_host (a HOST function of the C ABI) against face lists produced by the reference's
+    own data_util.mesh_get_neighbor_np (tests/golden/patches_n8.npz, oracle/gen_golden.py:gen_patches)."""
+    from geobi_gnn_amd import meshgen, patches
+    from helpers import load_fixture
+    fx = load_fixture('patches_n8.npz')
+    faces = fx['faces']
+    V = fx['points'].shape[0]
+    vf = meshgen.vertex_faces(faces.astype(np.int64), V)
+    counts = (vf >= 0).sum(1)
+    rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    lst = vf[vf >= 0].astype(np.int32)                       # row-major: per vertex, in row order
+    fv = np.ascontiguousarray(faces, dtype=np.int32)
+    off = 0
+    for seed, (nf, nv) in zip(fx['seeds'], fx['sizes']):
+        got = patches.patch_grow(fv, rowptr, lst, int(seed), neighbor_count=int(fx['sub_size']))
+        assert np.array_equal(got, fx['select_faces'][off:off + nf])
+        off += nf
+    assert np.array_equal(patches.patch_grow(fv, rowptr, lst, 5, ring_count=2), fx['ring2_from_face5'])
+    # unlimited growth reaches every face of the (connected) sphere exactly once
+    full = patches.patch_grow(fv, rowptr, lst, 0)
+    assert full.shape[0] == faces.shape[0] and np.unique(full).shape[0] == faces.shape[0]
