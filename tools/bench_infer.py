@@ -5,7 +5,7 @@ Forward under no_grad + 60-sweep vertex update (test_dual.py:44-72), inputs resi
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from geobi_gnn_amd import network, meshgen, infer, _lib as L
+from geobi_gnn_amd import network, meshgen, infer, patches, _lib as L
 import ctypes
 
 dev = torch.device('cuda:0')
@@ -45,4 +45,20 @@ for name, n, reps in (('configs[1] single mesh n=32', 32, 20), ('configs[3] larg
                 'aggregate_kernel': {'C': best[0], 'launches': best[3], 'avg_us': round(best[1] * 1e3 / best[3], 2),
                                      'algorithmic_GBps': round(best[2] / (best[1] * 1e-3) / 1e9, 1),
                                      'frac_of_8TBps': round(best[2] / (best[1] * 1e-3) / 1e9 / 8000, 3)}})
+# end to end from the raw mesh (points + faces already in HBM): device preprocessing (graphs, normals,
+# bilateral weights), optional patch split, network, merge, 60-sweep vertex update
+for name, n, sub, reps in (('configs[1] n=32 mesh -> denoised vertices', 32, 20480, 10),
+                           ('configs[3] n=87 mesh -> denoised vertices, unsplit (sub_size=200000)', 87, 200000, 5),
+                           ('configs[3] n=87 mesh -> denoised vertices, split at sub_size=20000', 87, 20000, 3)):
+    noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed=7)
+    pts = torch.from_numpy(noisy).to(dev)
+    fv = torch.from_numpy(faces).to(dev).int()
+    gt = torch.from_numpy(clean).to(dev)
+    r = patches.predict_mesh(net, pts, fv, sub_size=sub, gt_points=gt)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        r = patches.predict_mesh(net, pts, fv, sub_size=sub)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / reps
+    out.append({'workload': name, 'faces': int(faces.shape[0]), 'patches': r['n_patches'],
+                'end_to_end_ms': round(t * 1e3, 3), 'k_faces_per_s': round(faces.shape[0] / t / 1e3, 1)})
 print(json.dumps(out, indent=1))
