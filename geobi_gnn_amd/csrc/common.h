@@ -95,6 +95,7 @@ static inline size_t gemm_nn_fixed_ws_bytes(int64_t M, int N, int slices) {
 int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float* C, int ldc, int M, int N, int K,
             const GemmEpilogue& ep, hipStream_t s);
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M);
+size_t gemm_tn_ws_bytes_any_width(int I, int J, int64_t M);   // max over column widths 1..J
 enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1, TN_DU_DC = 2 };
 struct TnOutput {
   int mode = TN_PLAIN;

@@ -553,7 +553,7 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.wp = a.take<float>((size_t)ldr * Cin);
   b.tn_bytes = gemm_tn_ws_bytes(Kp + 1, Cout, N);           // [z | 1]^T g   (side stream)
   b.tn_ws = a.take<char>(b.tn_bytes);
-  b.tn_bytes2 = gemm_tn_ws_bytes(2 * HP, Cin + 1, N);        // [dp | dcs]^T [x | 1]
+  b.tn_bytes2 = gemm_tn_ws_bytes_any_width(2 * HP, Cin + 1, N);   // [dp | dcs]^T [x | 1], per input half
   b.tn_ws2 = a.take<char>(b.tn_bytes2);
   size_t g1 = gemm_nn_ws_bytes(N, Kp), g2 = gemm_nn_ws_bytes(N, Cin);
   b.gemm_bytes = g1 > g2 ? g1 : g2;

@@ -643,6 +643,17 @@ size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
   return align_up((size_t)by * I * J * sizeof(float)) + 256;
 }
 
+// Upper bound over every column width J' <= J the caller may pass for the same (I, M): the conv backward
+// issues du = dp^T [x | 1] once per input half when the layer reads a split (skip, up) input.
+size_t gemm_tn_ws_bytes_any_width(int I, int J, int64_t M) {
+  size_t best = 0;
+  for (int j = 1; j <= J; ++j) {
+    size_t b = gemm_tn_ws_bytes(I, j, M);
+    if (b > best) best = b;
+  }
+  return best;
+}
+
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
             const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s) {
   if (I <= 0 || J <= 0) return 0;

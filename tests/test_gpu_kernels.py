@@ -464,3 +464,29 @@ def test_sort_free_pool_edge_equals_radix_path(dev):
     gr = Graph.from_edge_index(ei.to(dev), 201)
     cnew, coarse, _, raw, _ = net_util._coarsen(gr, None)
     assert coarse.N == 200 and coarse.E == 2 * 199
+
+
+def test_feast_split_input_equals_concatenated_at_scale(dev):
+    """A (skip, up) input pair gives the same layer as the concatenated input, forward and backward, on a
+    graph large enough that the weight-gradient GEMMs of the two halves plan more node slices than the
+    concatenated shape would (regression: their slab workspace was sized for the concatenated width only)."""
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    n, cin, cout = 126000, 128, 64
+    ei = _sym_graph(n, 300000, seed=9).to(dev)
+    torch.manual_seed(3)
+    conv = FeaStConv(cin, cout, 9).to(dev)
+    x = torch.randn(n, cin, device=dev)
+    gout = torch.randn(n, cout, device=dev)
+    xa = x.clone().requires_grad_(True)
+    out = conv(xa, ei, slope=0.2)
+    out.backward(gout)
+    ref = {k: p.grad.clone() for k, p in conv.named_parameters()}
+    conv.zero_grad(set_to_none=True)
+    h1 = x[:, :64].clone().requires_grad_(True)
+    h2 = x[:, 64:].clone().requires_grad_(True)
+    out2 = conv(h1, ei, x2=h2, slope=0.2)
+    out2.backward(gout)
+    assert rel_err(out2.detach(), out.detach()) < 1e-6
+    assert rel_err(torch.cat([h1.grad, h2.grad], 1), xa.grad) < 1e-6
+    for k, p in conv.named_parameters():
+        assert rel_err(p.grad, ref[k]) < 1e-5, k
