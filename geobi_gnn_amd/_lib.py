@@ -12,7 +12,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'geobi_hip.h')
-LIB_PATH = os.path.join(_PKG, 'libgeobi_hip.so')
+# GEOBI_LIB: load another build of the same ABI (A/B timing of two builds on one box)
+LIB_PATH = os.environ.get('GEOBI_LIB') or os.path.join(_PKG, 'libgeobi_hip.so')
 
 
 class GeobiError(RuntimeError):
