@@ -61,6 +61,7 @@ void prof_end(int kernel, hipStream_t s) {
 
 // ------------------------------------------------------------------------- side stream
 static int g_overlap = 1;
+static int g_defer = 0;     // 1: backward calls fork but do not join; the caller joins once (geobi_side_join)
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
 
@@ -87,7 +88,7 @@ int side_wait_main(const Fork& f, hipStream_t main) {
 }
 
 int join_side_stream(const Fork& f, hipStream_t main) {
-  if (f.side == nullptr) return 0;
+  if (f.side == nullptr || g_defer) return 0;
   GEOBI_HIP(hipEventRecord(f.join, f.side));
   GEOBI_HIP(hipStreamWaitEvent(main, f.join, 0));
   return 0;
@@ -392,6 +393,18 @@ int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, i
   o.C = C;
   o.ldc = ldc;
   return gemm_tn(A, lda, B, ldb, M, I, J, -1, -1, o, ws, ws_bytes, S(stream));
+}
+
+int geobi_side_defer(int on) {
+  g_defer = on ? 1 : 0;
+  return 0;
+}
+
+int geobi_side_join(void* stream) {
+  if (g_side == nullptr) return 0;          // nothing was ever forked
+  GEOBI_HIP(hipEventRecord(g_join_ev, g_side));
+  GEOBI_HIP(hipStreamWaitEvent(S(stream), g_join_ev, 0));
+  return 0;
 }
 
 int geobi_set_overlap(int enable) {

@@ -9,6 +9,8 @@ geobi_head_fwd, the centroid/normal coupling inside geobi_face_geom_fwd.
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -116,6 +118,11 @@ class DualGNN(nn.Module):
         return verts, normals, tape
 
 
+# GEOBI_DEFER_JOIN=1: join the weight-gradient side stream once per backward instead of once per layer
+# (experimental; measured neutral-to-slower on the bench workload)
+_DEFER_JOIN = os.environ.get('GEOBI_DEFER_JOIN', '0') == '1'
+
+
 class DualGNNFn(torch.autograd.Function):
     """DualGNN as a single autograd node.  Inputs after the three leading objects are the module's
     parameters (so autograd routes their gradients); the backward replays the op tape."""
@@ -135,7 +142,9 @@ class DualGNNFn(torch.autograd.Function):
             seeds[id(ctx.verts)] = g_verts.contiguous()
         if g_normals is not None:
             seeds[id(ctx.normals)] = g_normals.contiguous()
-        leaf = ctx.tape.backward(seeds)
+        with ops.deferred_side_join(enable=_DEFER_JOIN):
+            leaf = ctx.tape.backward(seeds, clear=False)
+        ctx.tape.nodes = []
         ctx.tape = ctx.verts = ctx.normals = None
         return (None, None, None) + tuple(leaf.get(k) for k in ctx.param_ids)
 

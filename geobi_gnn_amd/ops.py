@@ -51,8 +51,9 @@ class Tape(object):
             self.live.add(id(out))
         return out
 
-    def backward(self, seeds):
-        """seeds: {id(tensor): grad}.  Returns {id(leaf tensor): grad} for leaves with requires_grad."""
+    def backward(self, seeds, clear=True):
+        """seeds: {id(tensor): grad}.  Returns {id(leaf tensor): grad} for leaves with requires_grad.
+        clear=False keeps the recorded nodes (and the tensors they saved) alive for the caller to drop."""
         grads = dict(seeds)
         leaf = {}
         for fn, ctx, args, out in reversed(self.nodes):
@@ -68,11 +69,41 @@ class Tape(object):
                     grads[k] = gi if k not in grads else grads[k] + gi
                 elif a.requires_grad:
                     leaf[k] = gi if k not in leaf else leaf[k] + gi
-        self.nodes = []
+        if clear:
+            self.nodes = []
         return leaf
 
 
 _ACTIVE_TAPE = [None]
+
+# Deferred side-stream join (geobi_side_defer): while a list is installed here, backward ops park every
+# buffer the side stream may still be reading (workspaces, incoming gradients) in it; whoever installed
+# it joins the side stream and only then drops the list.
+_SIDE_KEEP = [None]
+
+
+class deferred_side_join(object):
+    """with deferred_side_join(): ... -- weight-gradient GEMMs of all backward calls inside queue on the
+    library's side stream without per-call joins; one join on exit."""
+
+    def __init__(self, enable=True):
+        self.enable = enable
+
+    def __enter__(self):
+        self.prev = _SIDE_KEEP[0]
+        if self.enable and self.prev is None:
+            _SIDE_KEEP[0] = []
+            L.call('geobi_side_defer', 1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.enable and self.prev is None:
+            try:
+                L.call('geobi_side_defer', 0)
+                L.call('geobi_side_join', L.stream())
+            finally:
+                _SIDE_KEEP[0] = None
+        return False
 
 
 def apply_op(fn, *args):
@@ -175,6 +206,8 @@ class FeastConvFn(Function):
                L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
                ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(wf), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
                L.ptr(du), L.ptr(dc), L.ptr(dbias), L.ptr(ws), ws.numel(), L.stream())
+        if _SIDE_KEEP[0] is not None:
+            _SIDE_KEEP[0].append((ws, gout, dlin, du, dc, dbias))
         return (dxa, dxb) + ret + (None, None)
 
 

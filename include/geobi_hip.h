@@ -273,6 +273,12 @@ int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, i
  * library-owned non-blocking HIP stream, forked from and joined back into `stream` INSIDE the call
  * (event wait on both ends), so the caller's stream semantics are unchanged.  0 disables it.     */
 int geobi_set_overlap(int enable);
+/* Deferred join (experimental, off by default): with geobi_side_defer(1) a backward call still forks the
+ * side stream from `stream` but returns WITHOUT joining it.  The caller then owns the hazard: every buffer
+ * handed to those calls must stay allocated and untouched until geobi_side_join(stream) has been enqueued
+ * (it makes `stream` wait for everything on the side stream).                                          */
+int geobi_side_defer(int on);
+int geobi_side_join(void* stream);
 
 /* ---------------------------------------------------------------- measurement --------------
  * When enabled, the selected kernel family is bracketed with HIP events on its launch stream
