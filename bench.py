@@ -217,7 +217,8 @@ def main():
     net = network.DualGNN().to(device)
     flat = FlatParameters(net)            # one flat parameter + one flat gradient bucket
     bucket = flat.bucket
-    opt = torch.optim.Adam(flat.parameters(), lr=1e-3)
+    # same update rule as the reference's torch.optim.Adam(lr=1e-3) (train_dual.py:162), single-kernel form
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=torch.cuda.is_available())
     dv, df, edges = make_batch(rank, device, args.freq)
 
     log('rank %d: batch resident (%d edges), warming up' % (rank, edges))

@@ -62,7 +62,7 @@ def main():
     flat = FlatParameters(net)
     params = flat.parameters()
     if opt.optimizer == 'adam':
-        optimizer = torch.optim.Adam(params, lr=opt.lr)
+        optimizer = torch.optim.Adam(params, lr=opt.lr, fused=True)
     elif opt.optimizer == 'sgd':
         optimizer = torch.optim.SGD(params, lr=opt.lr, momentum=0.9)
     else:
