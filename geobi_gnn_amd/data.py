@@ -144,3 +144,47 @@ def union_batch(dual_list):
     data_v.mesh_ptr = torch.tensor(ptr_v, dtype=torch.long)
     data_f.mesh_ptr = torch.tensor(ptr_f, dtype=torch.long)
     return data_v, data_f
+
+
+# ------------------------------------------------------------------- processed-file cache
+# The reference caches every preprocessed (sub)mesh as ``torch.save((data_v, data_f), name.pt)`` of pickled
+# PyG ``Data`` objects (/root/reference/code/dataset.py:153,182; read back at :276).  Unpickling needs PyG and
+# executes code from the file; this cache holds the same fields as a plain {name: tensor | number | str}
+# dict, so ``torch.load(..., weights_only=True)`` reads it.
+_SCALARS = (int, float, str, bool)
+
+
+def _data_to_dict(d):
+    out = {}
+    for k in d.keys():
+        v = getattr(d, k)
+        if torch.is_tensor(v):
+            out[k] = v.detach().cpu()
+        elif isinstance(v, _SCALARS):
+            out[k] = v
+        elif isinstance(v, dict) and k == 'meta':
+            out[k] = {mk: (mv.detach().cpu() if torch.is_tensor(mv) else mv) for mk, mv in v.items()}
+    return out
+
+
+def _data_from_dict(dct):
+    d = Data()
+    for k, v in dct.items():
+        setattr(d, k, v)
+    return d
+
+
+def save_processed(dual_data, path):
+    """(data_v, data_f) -> one ``.pt`` file (tensors moved to the CPU; loop-free CSR-built graphs are stored
+    through their materialised ``edge_index``)."""
+    torch.save({'format': 'geobi-dual-v1', 'v': _data_to_dict(dual_data[0]), 'f': _data_to_dict(dual_data[1])}, path)
+
+
+def load_processed(path, device=None):
+    obj = torch.load(path, map_location='cpu', weights_only=True)
+    if not isinstance(obj, dict) or obj.get('format') != 'geobi-dual-v1':
+        raise ValueError('%s is not a geobi processed file' % path)
+    dv, df = _data_from_dict(obj['v']), _data_from_dict(obj['f'])
+    if device is not None:
+        dv, df = dv.to(device), df.to(device)
+    return dv, df

@@ -268,3 +268,25 @@ def test_patch_growth_matches_reference_fixture():
     # unlimited growth reaches every face of the (connected) sphere exactly once
     full = patches.patch_grow(fv, rowptr, lst, 0)
     assert full.shape[0] == faces.shape[0] and np.unique(full).shape[0] == faces.shape[0]
+
+
+def test_processed_file_round_trip(tmp_path):
+    """The processed-mesh cache (counterpart of dataset.py:153,182,276) loads with weights_only=True."""
+    from geobi_gnn_amd import meshgen
+    from geobi_gnn_amd.data import save_processed, load_processed
+    dv, df = meshgen.synthetic_dual_data(3, 0.2, seed=2)
+    path = str(tmp_path / 'ico3.pt')
+    save_processed((dv, df), path)
+    lv, lf = load_processed(path)
+    for a, b in ((dv, lv), (df, lf)):
+        assert set(a.keys()) == set(b.keys())
+        for k in a.keys():
+            va, vb = getattr(a, k), getattr(b, k)
+            if torch.is_tensor(va):
+                assert torch.equal(va, vb), k
+            elif isinstance(va, dict):
+                assert set(va) == set(vb) and all(torch.equal(va[m], vb[m]) if torch.is_tensor(va[m]) else va[m] == vb[m]
+                                                  for m in va)
+            else:
+                assert va == vb, k
+    assert lv.num_nodes == dv.num_nodes and lf.fv_indices.dtype == torch.int64
