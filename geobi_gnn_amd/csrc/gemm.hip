@@ -609,6 +609,11 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   // one-tile-per-wave shapes: 64-deep k-tiles when there is k to cover (half the barriers per MFMA and
   // twice the prefetch distance)
   const bool deep = k_chunk >= 128;
+  // Short reductions (K <= 64: dz = g Wf^T) are bound by writing the output; big register tiles buy no
+  // reuse there and only lower the number of blocks in flight: 64 x 64 tiles measured 10-20 % faster.
+  if (K <= 64 && N > 64) {
+    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);
+  } else
   if (big_blocks >= 384) {
     if (N > 64)
       GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
