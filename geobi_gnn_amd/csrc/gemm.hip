@@ -583,8 +583,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, N > 64 ? 128 : (N > 32 ? 64 : 32));
   int slices = 1, k_chunk = K;
   float* partial = nullptr;
-  int64_t blocks_small = (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256)
-                             ? (int64_t)cdiv(M, 64) * cdiv(N, 64) : (int64_t)cdiv(M, 32) * cdiv(N, 128);
+  const int64_t blocks_small = N <= 32 ? (int64_t)cdiv(M, 128) : (int64_t)cdiv(M, 64) * cdiv(N, 64);   // tiles below
   if (ep.fixed_slices > 0) {
     if (ep.fixed_slices > 1 && ep.ws != nullptr) {
       k_chunk = ((K + ep.fixed_slices - 1) / ep.fixed_slices + 63) / 64 * 64;
@@ -611,22 +610,25 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   const bool deep = k_chunk >= 128;
   // Short reductions (K <= 64: dz = g Wf^T) are bound by writing the output; big register tiles buy no
   // reuse there and only lower the number of blocks in flight: 64 x 64 tiles measured 10-20 % faster.
-  if (K <= 64 && N > 64) {
-    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);
-  } else
-  if (big_blocks >= 384) {
-    if (N > 64)
-      GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);  // 128 x 128
-    else if (N > 32)
-      GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32);  // 128 x 64
-    else if (deep)
-      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 64);  // 128 x 32
-    else
-      GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);
-  } else if (N <= 64 || (int64_t)cdiv(M, 64) * cdiv(N, 64) >= 256) {
-    if (deep) GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 64); else GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);    // 64 x 64
+  // Tile shape by measurement on this path's shapes (config sweeps of tools/gemm_bench.py, section 6 of
+  // DESIGN.md): one 32 x 32 tile per wave almost everywhere -- the grids here are a few blocks per CU, so
+  // more, smaller blocks beat register-tile reuse; the 128-row tiles only pay from ~10^5 rows on.
+  //   N <= 32           128 x 32   (four row tiles, the narrow output uses every wave)
+  //   N <= 64           64 x 64, or 128 x 64 from 98 304 rows
+  //   N  > 64           64 x 64, or 128 x 128 from 81 920 rows when the reduction is long (K > 64: short
+  //                     reductions -- dz = g Wf^T -- are bound by writing the output)
+  // 64-deep k-tiles from K >= 512 (half the barriers per MFMA); the k order is the same for every shape,
+  // so results do not depend on the choice.
+  if (N <= 32) {
+    GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);
+  } else if (N <= 64 && M >= 98304) {
+    GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32);
+  } else if (N > 64 && K > 64 && M >= 81920) {
+    GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16);
+  } else if (deep && K >= 512) {
+    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 64);
   } else {
-    if (deep) GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 64); else GEOBI_GEMM_LAUNCH(1, 4, 1, 1, 32);    // 32 x 128
+    GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32);
   }
 #undef GEOBI_GEMM_LAUNCH
 #undef GEOBI_GEMM_LAUNCH_F
