@@ -619,7 +619,16 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
   //                     reductions -- dz = g Wf^T -- are bound by writing the output)
   // 64-deep k-tiles from K >= 512 (half the barriers per MFMA); the k order is the same for every shape,
   // so results do not depend on the choice.
-  if (N <= 32) {
+  static const int forced = [] { const char* f = getenv("GEOBI_NN_CFG"); return f ? atoi(f) : 0; }();
+  if (forced) {                 // tuning knob for tools/nn_cfg_sweep.py: force one tile shape for every call
+    switch (forced) {
+      case 1: GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 32); break;
+      case 2: GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32); break;
+      case 4: GEOBI_GEMM_LAUNCH(2, 2, 2, 2, 16); break;
+      case 5: GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32); break;
+      default: GEOBI_GEMM_LAUNCH(2, 2, 1, 1, 64); break;
+    }
+  } else if (N <= 32) {
     GEOBI_GEMM_LAUNCH(4, 1, 1, 1, 32);
   } else if (N <= 64 && M >= 98304) {
     GEOBI_GEMM_LAUNCH(2, 2, 2, 1, 32);

@@ -1,3 +1,8 @@
+"""Tile-shape sweep of the NN GEMM on this path's shapes: run once per GEOBI_NN_CFG value (1: 64x64 k32,
+2: 128x64, 4: 128x128, 5: 128x32, 6: 64x64 k64; unset: the library's own choice) and compare the lines.
+
+  for c in "" 1 2 4 5 6; do GEOBI_NN_CFG=$c python tools/nn_cfg_sweep.py; done
+"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geobi_gnn_amd import _lib as L
