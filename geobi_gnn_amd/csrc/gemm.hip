@@ -537,9 +537,12 @@ TnPlan plan_tn(const float* A, int lda, int I, int J, int64_t M, int ones_row) {
   p.tiles_i = cdiv(I, 32 * p.ti);
   p.tiles_j = cdiv(J, 32 * p.tj);
   int tiles = p.tiles_i * p.tiles_j;
-  // About two blocks per CU in ONE resident round (a second, partial round would idle most CUs for a
+  // One to two blocks per CU in ONE resident round (a second, partial round would idle most CUs for a
   // whole block time; more, shorter slices only add slab traffic), each wave taking >= 64 nodes.
-  const int64_t capacity = 512;
+  static const int64_t cap_env = [] { const char* f = getenv("GEOBI_TN_CAP"); return f ? atoll(f) : 0ll; }();
+  // GEOBI_TN_CAP: tuning knob (tools/tn_cap_sweep.py).  Few output tiles (du/dc, narrow dWf): the slab
+  // reduction is a chain of dependent loads per output, so half the slabs measured ~15 % faster overall.
+  const int64_t capacity = cap_env > 0 ? cap_env : (tiles <= 3 ? 256 : 512);
   int64_t by = capacity / (tiles > 0 ? tiles : 1);
   if (by < 1) by = 1;
   int64_t max_by = (M + 255) / 256;                  // 4 waves x 64 nodes per block at least
