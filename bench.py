@@ -111,7 +111,7 @@ def measure_mfma(net, bucket, opt, dv, df, steps=3):
         train_step(net, bucket, opt, dv, df, collective=False)
     torch.cuda.synchronize()
     out = {'bound': 'mfma', 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'pmc': 'profiles/r01_pmc_gemm_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_mfma.py)'}
+           'pmc': 'profiles/r01_pmc_gemm_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32; tools/pmc_mfma.py)'}
     for name, tag in (('gemm_nn', 1), ('gemm_tn', 2)):
         n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'prof_collect')

@@ -8,7 +8,10 @@ rocprofv3 --pmc pass over the bench workload:
 
 Per kernel (all launches of the run summed):
   flops         = 512 * SQ_INSTS_VALU_MFMA_MOPS_F32   (one MOP = 512 flop; a 32x32x2 f32 MFMA is 8 MOPs)
-  mfma_util     = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)   (the gfx94x MfmaUtil formula)
+  mfma_busy     = SQ_VALU_MFMA_BUSY_CYCLES / (kernel ns * 2.4 GHz * 1024 SIMDs): fraction of the chip's MFMA issue
+                  slots in use at the nominal clock (64 cycles per 32x32x2 f32 MFMA).  The gfx94x MfmaUtil formula
+                  divides by GRBM_GUI_ACTIVE * CUs * 4 instead; on gfx950 GRBM_GUI_ACTIVE comes back summed over the
+                  8 XCDs (~22 counts per ns), which makes that figure ~9x too small, so it is not reported.
   tflops        = flops / kernel time (End - Start timestamps of the same dispatches), against the 157.3 TFLOP/s
                   fp32 MFMA peak of MI355X_MICROARCH.md
 These GEMMs are K<=1152, N<=128 with 1e3..3e5 rows: HBM / launch bound, so the utilisation is low by
@@ -45,7 +48,7 @@ def main(src, dst):
             acc[k]['launches'] += 1
     out = {'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, '
                      'bench.py --steps 3 --warmup 1 (4 steps of 4 x icosphere n=32)',
-           'formulas': 'flops = 512*MOPS_F32; mfma_util = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE*256*4); peak 157.3 TFLOP/s fp32 MFMA',
+           'formulas': 'flops = 512*MOPS_F32; mfma_busy = MFMA_BUSY_CYCLES / (ns * 2.4 * 1024 SIMDs); peak 157.3 TFLOP/s fp32 MFMA',
            'note': 'kernel time under counter collection is serialised and slower than the un-profiled run', 'kernels': {}}
     fam = collections.defaultdict(lambda: collections.defaultdict(float))
     for k, c in sorted(acc.items()):
@@ -57,7 +60,7 @@ def main(src, dst):
             'launches': int(c['launches']), 'avg_us': round(c['ns'] / 1e3 / c['launches'], 2),
             'gflop_per_launch': round(flops / 1e9 / c['launches'], 4),
             'tflops': round(flops / c['ns'] / 1e3, 2), 'frac_of_peak': round(flops / c['ns'] / 1e3 / PEAK_TFLOPS, 4),
-            'mfma_util': round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 256 * 4), 4)}
+            'mfma_busy': round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['ns'] * 2.4 * 1024), 4)}
     json.dump(out, open(dst, 'w'), indent=1)
     for k, v in out['kernels'].items():
         if 'all inst' in k:
