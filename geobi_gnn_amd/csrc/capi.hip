@@ -138,6 +138,8 @@ int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst
   return gather_f32(src, idx, n, dst, S(stream));
 }
 
+size_t geobi_feast_wpack_floats(int Cin, int Cout) { return feast_wpack_floats(Cin, Cout); }
+
 int geobi_feast_ldz(int Cin) { return feast_ldz(Cin); }
 size_t geobi_feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) { return feast_fwd_ws_bytes(N, Cin, Cout); }
 
@@ -193,10 +195,10 @@ int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const floa
 }
 
 size_t geobi_relabel_ws_bytes(int64_t N) { return relabel_ws_bytes(N); }
-int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws,
-                          size_t ws_bytes, void* stream) {
+int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count,
+                          void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(cluster); NOTNULL(cnew); NOTNULL(count);
-  return relabel_compact(cluster, N, cnew, count, ws, ws_bytes, S(stream));
+  return relabel_compact(cluster, N, rep_is_self, cnew, count, ws, ws_bytes, S(stream));
 }
 
 size_t geobi_segment_csr_ws_bytes(int64_t n) { return segment_csr_ws_bytes(n); }

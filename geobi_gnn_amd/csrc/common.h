@@ -87,6 +87,11 @@ static inline size_t gemm_nn_ws_bytes(int64_t M, int N) {
   return (M * N < (int64_t)2200000) ? align_up((size_t)8 * M * N * sizeof(float)) + 256 : 256;
 }
 // forward GEMM of a FeaSt layer: the split is a function of the layer shape only
+// packed-weight buffer shared by forward and backward: Wf [ldz(Cin), Cout] for z Wf / g Wf^T, then
+// W' [ldr(Cout), Cin] = [lin.weight ; u.weight ; 0] for dx = r' W'
+static inline size_t feast_wpack_floats(int Cin, int Cout) {
+  return (size_t)((GEOBI_H * Cin + 3) / 4 * 4) * Cout + (size_t)(GEOBI_H * Cout + 2 * GEOBI_HP) * Cin;
+}
 static inline int feast_fwd_slices(int Kp, int Cout) { return Kp >= 1024 ? 4 : ((Kp >= 512 && Cout >= 64) ? 2 : 1); }
 static inline size_t gemm_nn_fixed_ws_bytes(int64_t M, int N, int slices) {
   size_t b = (size_t)slices * M * N * sizeof(float);
@@ -133,7 +138,8 @@ size_t match_ws_bytes(int64_t N);
 int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                      int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
 size_t relabel_ws_bytes(int64_t N);
-int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws, size_t ws_bytes,
+int relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count, void* ws,
+                    size_t ws_bytes,
                     hipStream_t s);
 size_t segment_csr_ws_bytes(int64_t n);
 int segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,

@@ -421,6 +421,26 @@ __global__ void pack_wprime_kernel(const float* __restrict__ lin_w, const float*
   wp[idx] = v;
 }
 
+// forward: both packed forms in one launch (the backward's W' costs a second launch otherwise)
+__global__ void pack_weights_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w, int Cin, int Cout,
+                                    int Kp, int ldr, float* __restrict__ wf, float* __restrict__ wp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nwf = Kp * Cout;
+  if (idx < nwf) {
+    int kk = idx / Cout, o = idx % Cout;
+    int h = kk / Cin, k = kk % Cin;
+    wf[idx] = (h < H) ? lin_w[((size_t)h * Cout + o) * Cin + k] : 0.f;
+    return;
+  }
+  idx -= nwf;
+  if (idx >= ldr * Cin) return;
+  int r = idx / Cin, k = idx % Cin;
+  float v = 0.f;
+  if (r < H * Cout) v = lin_w[(size_t)r * Cin + k];
+  else if (r < H * Cout + H) v = u_w[(size_t)(r - H * Cout) * Cin + k];
+  wp[idx] = v;
+}
+
 __global__ void lrelu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out, float slope, int64_t n,
                                  float* __restrict__ g) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,7 +537,13 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   const size_t gws = gemm_nn_fixed_ws_bytes(N, Cout, fwd_slices);
   void* gemm_ws = a.take<char>(gws);
   GEOBI_REQUIRE(a.ok() && wf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
-  pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, wf);
+  if (wf_out != nullptr) {     // kept for the backward: Wf and W' side by side
+    const int ldr_ = feast_ldr(Cout);
+    pack_weights_kernel<<<cdiv((int64_t)Kp * Cout + (int64_t)ldr_ * Cin, 256), 256, 0, s>>>(
+        lin_w, u_w, Cin, Cout, Kp, ldr_, wf, wf + (size_t)Kp * Cout);
+  } else {
+    pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, wf);
+  }
   GEOBI_LAUNCH_OK();
   GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
   prof_begin(PROF_AGG_FWD, s, feast_agg_bytes(N, Ecap, Cin, Kp), Cin);
@@ -637,13 +663,16 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, s);
     prof_end(PROF_AGG_BWD, s);
     GEOBI_TRY(rc);
-    pack_wprime_kernel<<<cdiv((int64_t)ldr * Cin, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, ldr, b.wp);
-    GEOBI_LAUNCH_OK();
+    const float* wp = wf_saved ? wf_saved + (size_t)Kp * Cout : b.wp;
+    if (wf_saved == nullptr) {
+      pack_wprime_kernel<<<cdiv((int64_t)ldr * Cin, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, ldr, b.wp);
+      GEOBI_LAUNCH_OK();
+    }
     GemmEpilogue ep1;
     ep1.ws = b.gemm_ws;
     ep1.ws_bytes = b.gemm_bytes;
     if (Cb) { ep1.C1 = dxb; ep1.split = Ca; ep1.ldc1 = Cb; }
-    GEOBI_TRY(gemm_nn(b.rp, ldr, b.wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
+    GEOBI_TRY(gemm_nn(b.rp, ldr, wp, Cin, 0, dxa, Cb ? Ca : Cin, (int)N, Cin, ldr, ep1, s));
   }
   // the side stream's results (and its scratch) are handed back before the call returns
   GEOBI_TRY(join_side_stream(fk, s));

@@ -143,6 +143,12 @@ __global__ void match_finish_kernel(int N, const int* __restrict__ state, int* _
 }
 
 // ----------------------------------------------------------------------------- relabel
+// clusterings whose ids are member indices with cluster[id] == id (graclus: id = min member): no scatter
+__global__ void rep_self_flag_kernel(const int* __restrict__ cluster, int N, int* __restrict__ flag) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < N) flag[u] = cluster[u] == u ? 1 : 0;
+}
+
 __global__ void rep_flag_kernel(const int* __restrict__ cluster, int N, int* __restrict__ flag) {
   // flag every id that occurs (benign race: all writers store 1); ids must lie in [0, N)
   int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,8 +614,8 @@ size_t relabel_ws_bytes(int64_t N) {
   return align_up((size_t)N * sizeof(int)) * 2 + align_up(scan_temp_bytes<int>(N)) + 512;
 }
 
-int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws, size_t ws_bytes,
-                    hipStream_t s) {
+int relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
   GEOBI_REQUIRE(N > 0, "relabel: empty");
   Arena a(ws, ws_bytes);
   int* flag = a.take<int>(N);
@@ -618,8 +624,12 @@ int relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* c
   void* temp = a.take<char>(tb ? tb : 1);
   GEOBI_REQUIRE(a.ok() && flag, "relabel: workspace too small");
   int blocks = cdiv(N, 256);
-  GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int) * N, s));
-  rep_flag_kernel<<<blocks, 256, 0, s>>>(cluster, (int)N, flag);
+  if (rep_is_self) {
+    rep_self_flag_kernel<<<blocks, 256, 0, s>>>(cluster, (int)N, flag);
+  } else {
+    GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int) * N, s));
+    rep_flag_kernel<<<blocks, 256, 0, s>>>(cluster, (int)N, flag);
+  }
   GEOBI_LAUNCH_OK();
   GEOBI_HIP(exclusive_scan_int(temp, tb, flag, rank, N, s));
   relabel_apply_kernel<<<blocks, 256, 0, s>>>(cluster, flag, rank, (int)N, cnew, count);

@@ -58,7 +58,7 @@ class Graph(object):
     def _reverse_index(self):
         dev = self.device
         pos = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)[:self.E]
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag = torch.empty(1, dtype=torch.int32, device=dev)       # zeroed by the call
         L.call('geobi_csr_reverse_index', L.ptr(self.rowptr_out), L.ptr(self.ensure_rows()), L.ptr(self.col_out),
                self.E, L.ptr(pos), L.ptr(flag), L.stream())
         return pos, flag

@@ -48,15 +48,17 @@ def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None, status=None
     return cluster, status, state
 
 
-def relabel(cluster32, count=None):
-    """consecutive_cluster: dense ids; returns (cnew int32 [N], count int32 [1] on device)."""
+def relabel(cluster32, count=None, rep_is_self=False):
+    """consecutive_cluster: dense ids; returns (cnew int32 [N], count int32 [1] on device).
+    rep_is_self: every id is a member index with cluster[id] == id (a matching's min-member ids)."""
     n = cluster32.shape[0]
     dev = cluster32.device
     cnew = torch.empty(n, dtype=torch.int32, device=dev)
     if count is None:
         count = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = L.workspace(L.size_query('geobi_relabel_ws_bytes', n), dev)
-    L.call('geobi_relabel_compact', L.ptr(cluster32), n, L.ptr(cnew), L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
+    L.call('geobi_relabel_compact', L.ptr(cluster32), n, 1 if rep_is_self else 0, L.ptr(cnew), L.ptr(count), L.ptr(ws),
+           ws.numel(), L.stream())
     return cnew, count
 
 
@@ -94,6 +96,26 @@ def _pool_edge_rows(cnew32, sidx, graph, weight_sorted, ncount, count, overflow)
     return rowptr_c, row_c, col_c, w_c
 
 
+class _CounterPool(object):
+    """Zeroed int32[4] scratch for the pooling kernels' device-side counters.  One fill kernel per 256 quads
+    instead of one per pooling step: quads are handed out once and never reused; the backing tensor is
+    released when its last quad is."""
+
+    def __init__(self):
+        self.buf, self.used, self.key = None, 0, None
+
+    def take(self, device):
+        key = (device.type, device.index)
+        if self.buf is None or self.key != key or self.used >= self.buf.shape[0]:
+            self.buf, self.used, self.key = torch.zeros((256, 4), dtype=torch.int32, device=device), 0, key
+        q = self.buf[self.used]
+        self.used += 1
+        return q
+
+
+_counters = _CounterPool()
+
+
 def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
     """One pooling step on the structure: match (unless given) -> relabel -> pool_edge.
 
@@ -104,10 +126,10 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
         state, total = None, 0
         while True:
             # one int32[4] holds {undecided, N', E', overflow}: one fill, one device-to-host read per step
-            counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
+            counters = _counters.take(graph.device)
             cluster32, _, state = hip_match(graph, weight_sorted, rounds, state, status=counters[0:1])
             total += rounds
-            cnew, _ = relabel(cluster32, count=counters[1:2])
+            cnew, _ = relabel(cluster32, count=counters[1:2], rep_is_self=True)
             # inverse lists of the matching, sized by the fine node count (N' is still on the device)
             sidx = ops.SegmentIndex.from_matching(cnew, cluster32, graph.N)
             rowptr_c, row_c, col_c, w_c = _pool_edge_rows(cnew, sidx, graph, weight_sorted, counters[1:2],
@@ -124,7 +146,7 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
             rounds = min(rounds * 2, MATCH_ROUNDS_MAX - total)
         sidx.narrow(nc)
     else:
-        counters = torch.zeros(4, dtype=torch.int32, device=graph.device)
+        counters = _counters.take(graph.device)
         cnew, _ = relabel(cluster32, count=counters[1:2])
         rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
         _, nc, ec, _ = counters.tolist()
@@ -170,10 +192,23 @@ class PoolingLayer(nn.Module):
             self.att_r = nn.Parameter(torch.empty(1, in_channel))
             nn.init.xavier_uniform_(self.att_l.data, gain=1.414)
             nn.init.xavier_uniform_(self.att_r.data, gain=1.414)
-        self.unpooling_indices = None
+        self._unpool32 = self._unpool64 = None
         self.graclus_fn = None          # optional: callable(edge_index, weight, num_nodes) -> cluster
         self._last_clusters32 = None    # raw cluster vectors of the last forward
         self._unpool_index = None
+
+    @property
+    def unpooling_indices(self):
+        """Composed fine -> coarse index of the last forward (net_util.py:152-156), int64 like the reference
+        keeps it; converted from the int32 the kernels use on first read."""
+        if self._unpool64 is None and self._unpool32 is not None:
+            self._unpool64 = self._unpool32.long()
+        return self._unpool64
+
+    @unpooling_indices.setter
+    def unpooling_indices(self, value):
+        self._unpool64 = value
+        self._unpool32 = None if value is None else value.to(torch.int32)
 
     @property
     def last_clusters(self):
@@ -250,7 +285,7 @@ class PoolingLayer(nn.Module):
                 break
 
         clust = _compose(clusts)
-        self.unpooling_indices = clust.long()
+        self._unpool32, self._unpool64 = clust, None
         uidx = sidxs[0]
         for nxt in sidxs[1:]:
             uidx = ops.SegmentIndex.compose(uidx, nxt, clust)
@@ -261,7 +296,7 @@ class PoolingLayer(nn.Module):
         return out
 
     def unpooling(self, x):
-        if self.unpooling_indices is None:
+        if self._unpool32 is None:
             return x
         return ops.apply_op(ops.UnpoolFn, x, self._unpool_index)
 

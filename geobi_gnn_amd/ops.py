@@ -170,18 +170,23 @@ class FeastConvFn(Function):
         out = torch.empty((N, Cout), dtype=torch.float32, device=dev)
         p = torch.empty((N, HP), dtype=torch.float32, device=dev)
         z = torch.empty((N, ldz), dtype=torch.float32, device=dev)
-        wf = torch.empty((ldz, Cout), dtype=torch.float32, device=dev)      # packed weights, reused by the backward
+        # packed weights (Wf | W'), reused by the backward; not kept when nothing needs a gradient
+        wf = None
+        if any(ctx.needs_input_grad):
+            wf = torch.empty(L.size_query('geobi_feast_wpack_floats', Cin, Cout), dtype=torch.float32, device=dev)
         ws = L.workspace(L.size_query('geobi_feast_fwd_ws_bytes', N, Cin, Cout), dev)
         L.call('geobi_feast_fwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(lin_w), L.ptr(u_w), L.ptr(c), L.ptr(bias), Cout, float(slope), L.ptr(out), L.ptr(p), L.ptr(z),
                L.ptr(wf), L.ptr(ws), ws.numel(), L.stream())
-        ctx.graph, ctx.slope, ctx.has_b = g, float(slope), xb is not None
-        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z, wf)
+        ctx.graph, ctx.slope, ctx.has_b, ctx.has_wf = g, float(slope), xb is not None, wf is not None
+        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z, wf if wf is not None else p)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         xa, xb, lin_w, u_w, c, out, p, z, wf = ctx.saved_tensors
+        if not ctx.has_wf:
+            wf = None
         g = ctx.graph
         if not ctx.has_b:
             xb = None

@@ -70,11 +70,13 @@ int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst
  *   lin_w [9*Cout, Cin], u_w [9, Cin], c [9], bias [Cout]   (PyG >= 2.0 state-dict layout)
  *   forward saves p [N, 12] (x u^T) and z [N, geobi_feast_ldz(Cin)] (aggregated features) for the
  *   backward; `out` after the activation is needed by the backward when slope != 1.  wf (optional,
- *   [geobi_feast_ldz(Cin), Cout]) receives the packed weights in the forward and, handed back to the
- *   backward, saves repacking them (NULL: packed into the workspace on both sides).
+ *   geobi_feast_wpack_floats(Cin, Cout) floats) receives the packed weights -- Wf [ldz, Cout] followed by
+ *   W' = [lin.weight ; u.weight ; 0] [9 Cout + 24, Cin] -- in the forward and, handed back to the backward,
+ *   saves repacking them there (NULL: packed into the workspace on both sides).
  *   E = number of edges in the CSR (used for scratch sizing and byte accounting only).
  *   Supported channel counts: Cin, Cout in {6, 12, 32, 64, 128} (Cout: 32, 64, 128).           */
 int geobi_feast_ldz(int Cin);
+size_t geobi_feast_wpack_floats(int Cin, int Cout);
 size_t geobi_feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
 int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
                     const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
@@ -100,6 +102,9 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
  *                         receives a copy with the undecided nodes closed as singletons.
  * geobi_relabel_compact : torch_geometric consecutive_cluster (code/net_util.py:128): dense ids by
  *                         ascending cluster id; count[0] = number of clusters (device int32).
+ *                         rep_is_self != 0: the caller guarantees that every cluster id is the index of
+ *                         one of its own members with cluster[id] == id (true for graclus / the matching
+ *                         above: id = min member) -- saves the occupancy pass.
  * geobi_segment_csr     : inverse lists segment -> members (ascending), the sorted-segment form of
  *                         torch_scatter's index argument.
  * geobi_segment_max_*   : torch_scatter.scatter(reduce='max') + backward (code/net_util.py:134);
@@ -116,8 +121,8 @@ size_t geobi_match_ws_bytes(int64_t N);
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_relabel_ws_bytes(int64_t N);
-int geobi_relabel_compact(const int32_t* cluster, int64_t N, int32_t* cnew, int32_t* count, void* ws,
-                          size_t ws_bytes, void* stream);
+int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count,
+                          void* ws, size_t ws_bytes, void* stream);
 size_t geobi_segment_csr_ws_bytes(int64_t n);
 int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
                       size_t ws_bytes, void* stream);
