@@ -194,6 +194,16 @@ int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const floa
   return match_heavy_edge(rowptr, col, w, N, rounds, init, cluster, cluster_final, status, ws, ws_bytes, S(stream));
 }
 
+size_t geobi_match_coarsen_ws_bytes(int64_t N) { return match_coarsen_ws_bytes(N); }
+int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                        int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
+                        int32_t* counters, void* ws, size_t ws_bytes, void* stream) {
+  NOTNULL(rowptr); NOTNULL(state); NOTNULL(cluster_final); NOTNULL(cnew); NOTNULL(segptr);     // col: NULL when E = 0
+  NOTNULL(members); NOTNULL(counters); NOTNULL(ws);
+  return match_coarsen(rowptr, col, w, N, rounds, init, state, cluster_final, cnew, segptr, members, counters, ws,
+                       ws_bytes, S(stream));
+}
+
 size_t geobi_relabel_ws_bytes(int64_t N) { return relabel_ws_bytes(N); }
 int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count,
                           void* ws, size_t ws_bytes, void* stream) {

@@ -135,6 +135,10 @@ int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* co
 int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s);
 int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s);
 size_t match_ws_bytes(int64_t N);
+size_t match_coarsen_ws_bytes(int64_t N);
+int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                  int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
+                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s);
 int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                      int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
 size_t relabel_ws_bytes(int64_t N);

@@ -98,7 +98,7 @@ __global__ void match_round_kernel(const int* __restrict__ rowptr, const int* __
   if (cluster[u] >= 0) { prop_next[u] = -1; return; }
   int pv = prop_prev[u];
   if (pv == -1) { cluster[u] = u; prop_next[u] = -1; return; }
-  if (pv >= 0 && prop_prev[pv] == u) { cluster[u] = u < pv ? u : pv; prop_next[u] = -1; return; }
+  if (pv >= 0 && prop_prev[pv] == u) { cluster[u] = pv; prop_next[u] = -1; return; }    // state = partner
   int best = -1, ba = 0, bb = 0;
   float bw = 0.f;
   for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
@@ -111,21 +111,57 @@ __global__ void match_round_kernel(const int* __restrict__ rowptr, const int* __
   prop_next[u] = best;
 }
 
+// State of a node between calls (`cluster` of the launchers): -1 undecided, u closed as a singleton,
+// v != u matched with partner v.  The cluster id graclus reports is min(u, state).
+//
 // commit of the last round + count of nodes that are still undecided; `final` (optional) receives the
-// clustering with the undecided nodes closed as singletons
+// clustering with the undecided nodes closed as singletons; flag / sz (optional, both or neither):
+// flag[u] = u is the representative (smaller member) of its cluster, sz[u] = its cluster size (0 for non-reps)
 __global__ void match_commit_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
-                                    int* __restrict__ remaining, int* __restrict__ final) {
+                                    int* __restrict__ remaining, int* __restrict__ final, int* __restrict__ flag,
+                                    int* __restrict__ sz) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0 && flag) { flag[N] = 0; sz[N] = 0; }      // scan tails
+  if (u >= N) return;
+  int st = cluster[u];
+  if (st < 0) {
+    int v = prop[u];
+    if (v == -1) st = u;
+    else if (v >= 0 && prop[v] == u) st = v;
+    else atomicAdd(remaining, 1);
+    if (st >= 0) cluster[u] = st;
+  }
+  const int fin = st < 0 ? u : (u < st ? u : st);
+  if (final) final[u] = fin;
+  if (flag) {
+    const bool rep = fin == u;
+    flag[u] = rep ? 1 : 0;
+    sz[u] = rep ? ((st >= 0 && st != u) ? 2 : 1) : 0;
+  }
+}
+
+// dense ids + inverse lists of the matching from the two scans (rank of a representative, offset of its
+// members): cnew[u] = rank[rep(u)]; segment c = [rep, partner]; segptr[nc] = N closes the list
+__global__ void match_lists_kernel(const int* __restrict__ state, const int* __restrict__ final,
+                                   const int* __restrict__ rank, const int* __restrict__ offs, int N,
+                                   int* __restrict__ cnew, int* __restrict__ count, int* __restrict__ segptr,
+                                   int* __restrict__ members) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  int c = cluster[u];
-  if (c < 0) {
-    int v = prop[u];
-    if (v == -1) c = u;
-    else if (v >= 0 && prop[v] == u) c = u < v ? u : v;
-    else atomicAdd(remaining, 1);
-    if (c >= 0) cluster[u] = c;
+  const int rep = final[u];
+  cnew[u] = rank[rep];
+  if (rep == u) {
+    const int o = offs[u];
+    segptr[rank[u]] = o;
+    members[o] = u;
+    const int st = state[u];
+    if (st >= 0 && st != u) members[o + 1] = st;
   }
-  if (final) final[u] = c < 0 ? u : c;
+  if (u == N - 1) {
+    const int nc = rank[N];                            // exclusive scan over N + 1 entries: total at [N]
+    *count = nc;
+    segptr[nc] = N;
+  }
 }
 
 __global__ void match_init_kernel(int N, int init, int* __restrict__ cluster, int* __restrict__ prop,
@@ -139,7 +175,7 @@ __global__ void match_init_kernel(int N, int init, int* __restrict__ cluster, in
 
 __global__ void match_finish_kernel(int N, const int* __restrict__ state, int* __restrict__ cluster) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < N) { int c = state[u]; cluster[u] = c < 0 ? u : c; }
+  if (u < N) { int c = state[u]; cluster[u] = c < 0 ? u : (u < c ? u : c); }
 }
 
 // ----------------------------------------------------------------------------- relabel
@@ -515,6 +551,51 @@ __global__ __launch_bounds__(1024) void small_exclusive_scan_kernel(const int* _
   }
 }
 
+// Two independent exclusive scans in one launch (same walk as above without the prefetch; used for short arrays).
+__global__ __launch_bounds__(1024) void small_exclusive_scan2_kernel(const int* __restrict__ in_a,
+                                                                     const int* __restrict__ in_b,
+                                                                     int* __restrict__ out_a, int* __restrict__ out_b,
+                                                                     int64_t n) {
+  constexpr int EPT = 16, CHUNK = 1024 * EPT;
+  __shared__ int wsum[2][2][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry_a = 0, carry_b = 0, buf = 0;
+  for (int64_t base = 0; base < n; base += CHUNK, buf ^= 1) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+    int va[EPT], vb[EPT], ta = 0, tb = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const bool ok = i0 + q < n;
+      va[q] = ok ? in_a[i0 + q] : 0;
+      vb[q] = ok ? in_b[i0 + q] : 0;
+      ta += va[q];
+      tb += vb[q];
+    }
+    int ia = ta, ib = tb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int xa = __shfl_up(ia, d, 64), xb = __shfl_up(ib, d, 64);
+      if (lane >= d) { ia += xa; ib += xb; }
+    }
+    if (lane == 63) { wsum[buf][0][wave] = ia; wsum[buf][1][wave] = ib; }
+    __syncthreads();
+    int woa = 0, wob = 0, tota = 0, totb = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int xa = wsum[buf][0][w], xb = wsum[buf][1][w];
+      woa += w < wave ? xa : 0; wob += w < wave ? xb : 0;
+      tota += xa; totb += xb;
+    }
+    int ea = carry_a + woa + ia - ta, eb = carry_b + wob + ib - tb;
+    carry_a += tota; carry_b += totb;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      if (i0 + q < n) { out_a[i0 + q] = ea; out_b[i0 + q] = eb; }
+      ea += va[q]; eb += vb[q];
+    }
+  }
+}
+
 constexpr int64_t kSmallScan = 1 << 18;
 
 static hipError_t exclusive_scan_int(void* temp, size_t& tb, const int* in, int* out, int64_t n, hipStream_t s) {
@@ -605,7 +686,52 @@ int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, 
     match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, cluster, pn);
     int* t = pp; pp = pn; pn = t;
   }
-  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status, cluster_final);
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status, cluster_final, nullptr, nullptr);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+size_t match_coarsen_ws_bytes(int64_t N) {
+  return match_ws_bytes(N) + 5 * align_up((size_t)(N + 1) * sizeof(int)) + 2 * scan_ws_bytes(N + 1) + 1024;
+}
+
+// One pooling step's integer front end in one call: matching rounds, commit, dense relabel and the inverse
+// lists of the matching (what geobi_match_heavy_edge + geobi_relabel_compact + geobi_segment_csr_pairs
+// produce, 6 launches fewer).  counters[0] = undecided nodes, counters[1] = coarse node count.
+int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                  int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
+                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(N > 0 && rounds > 0, "match_coarsen: empty graph or no rounds");
+  Arena a(ws, ws_bytes);
+  int* prop0 = a.take<int>(N);
+  int* prop1 = a.take<int>(N);
+  int* flag = a.take<int>(N + 1);
+  int* sz = a.take<int>(N + 1);
+  int* rank = a.take<int>(N + 1);
+  int* offs = a.take<int>(N + 1);
+  size_t tb = scan_ws_bytes(N + 1);
+  void* temp_a = a.take<char>(tb);
+  void* temp_b = a.take<char>(tb);
+  GEOBI_REQUIRE(a.ok() && prop0, "match_coarsen: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const int blocks = cdiv(N, 256);
+  match_init_kernel<<<blocks, 256, 0, s>>>((int)N, init, state, prop0, counters);
+  int* pp = prop0;
+  int* pn = prop1;
+  for (int r = 0; r < rounds; ++r) {
+    match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, state, pn);
+    int* t = pp; pp = pn; pn = t;
+  }
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
+  GEOBI_LAUNCH_OK();
+  if (N + 1 <= 16384) {          // one chunk of the walk: both scans in one launch
+    small_exclusive_scan2_kernel<<<1, 1024, 0, s>>>(flag, sz, rank, offs, N + 1);
+    GEOBI_LAUNCH_OK();
+  } else {
+    GEOBI_TRY(scan_exclusive_i32(temp_a, tb, flag, rank, N + 1, s));
+    GEOBI_TRY(scan_exclusive_i32(temp_b, tb, sz, offs, N + 1, s));
+  }
+  match_lists_kernel<<<blocks, 256, 0, s>>>(state, cluster_final, rank, offs, (int)N, cnew, counters + 1, segptr,
+                                            members);
   GEOBI_LAUNCH_OK();
   return 0;
 }

@@ -12,6 +12,8 @@ deterministic greedy matching in descending edge-weight order (same objective, s
 ``cluster = min(u, v)`` labelling).  ``PoolingLayer.graclus_fn`` lets a caller supply cluster
 vectors instead (parity tests replay the reference's recorded clusters through it).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -46,6 +48,25 @@ def hip_match(graph, weight_sorted, rounds=MATCH_ROUNDS, state=None, status=None
     L.call('geobi_match_heavy_edge', L.ptr(graph.rowptr_out), L.ptr(graph.col_out), L.ptr(w), graph.N, rounds,
            1 if init else 0, L.ptr(state), L.ptr(cluster), L.ptr(status), L.ptr(ws), ws.numel(), L.stream())
     return cluster, status, state
+
+
+def hip_match_coarsen(graph, weight_sorted, counters, rounds=MATCH_ROUNDS, state=None):
+    """Matching + dense relabel + inverse lists in one library call (geobi_match_coarsen).
+
+    Returns (raw cluster int32 [N] (graclus ids), cnew int32 [N], SegmentIndex sized by N, state)."""
+    dev = graph.device
+    init = state is None
+    if init:
+        state = torch.empty(graph.N, dtype=torch.int32, device=dev)
+    cluster = torch.empty(graph.N, dtype=torch.int32, device=dev)
+    cnew = torch.empty(graph.N, dtype=torch.int32, device=dev)
+    sidx = ops.SegmentIndex(cnew, graph.N, build=False)
+    ws = L.workspace(L.size_query('geobi_match_coarsen_ws_bytes', graph.N), dev)
+    w = None if weight_sorted is None else weight_sorted.contiguous()
+    L.call('geobi_match_coarsen', L.ptr(graph.rowptr_out), L.ptr(graph.col_out), L.ptr(w), graph.N, rounds,
+           1 if init else 0, L.ptr(state), L.ptr(cluster), L.ptr(cnew), L.ptr(sidx.segptr), L.ptr(sidx.members),
+           L.ptr(counters), L.ptr(ws), ws.numel(), L.stream())
+    return cluster, cnew, sidx, state
 
 
 def relabel(cluster32, count=None, rep_is_self=False):
@@ -96,6 +117,9 @@ def _pool_edge_rows(cnew32, sidx, graph, weight_sorted, ncount, count, overflow)
     return rowptr_c, row_c, col_c, w_c
 
 
+_FUSED_COARSEN = os.environ.get('GEOBI_FUSED_COARSEN', '1') == '1'
+
+
 class _CounterPool(object):
     """Zeroed int32[4] scratch for the pooling kernels' device-side counters.  One fill kernel per 256 quads
     instead of one per pooling step: quads are handed out once and never reused; the backing tensor is
@@ -127,11 +151,13 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
         while True:
             # one int32[4] holds {undecided, N', E', overflow}: one fill, one device-to-host read per step
             counters = _counters.take(graph.device)
-            cluster32, _, state = hip_match(graph, weight_sorted, rounds, state, status=counters[0:1])
+            if _FUSED_COARSEN:
+                cluster32, cnew, sidx, state = hip_match_coarsen(graph, weight_sorted, counters, rounds, state)
+            else:
+                cluster32, _, state = hip_match(graph, weight_sorted, rounds, state, status=counters[0:1])
+                cnew, _ = relabel(cluster32, count=counters[1:2], rep_is_self=True)
+                sidx = ops.SegmentIndex.from_matching(cnew, cluster32, graph.N)
             total += rounds
-            cnew, _ = relabel(cluster32, count=counters[1:2], rep_is_self=True)
-            # inverse lists of the matching, sized by the fine node count (N' is still on the device)
-            sidx = ops.SegmentIndex.from_matching(cnew, cluster32, graph.N)
             rowptr_c, row_c, col_c, w_c = _pool_edge_rows(cnew, sidx, graph, weight_sorted, counters[1:2],
                                                           counters[2:3], counters[3:4])
             undecided, nc, ec, overflow = counters.tolist()

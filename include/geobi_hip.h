@@ -97,7 +97,8 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
  * geobi_match_heavy_edge: torch_cluster.graclus (code/net_util.py:127,325,353): heavy-edge matching,
  *                         cluster[u] = cluster[v] = min(u, v), unmatched -> own id.  Deterministic
  *                         (greedy in descending edge order).  init != 0 starts from scratch, init == 0
- *                         continues from `cluster` (< 0 = undecided); status[0] = nodes still undecided
+ *                         continues from `cluster` (the resumable state: -1 undecided, u closed as a
+ *                         singleton, v matched with partner v); status[0] = nodes still undecided
  *                         after `rounds` proposal rounds (0 = converged); cluster_final (optional)
  *                         receives a copy with the undecided nodes closed as singletons.
  * geobi_relabel_compact : torch_geometric consecutive_cluster (code/net_util.py:128): dense ids by
@@ -120,6 +121,16 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
 size_t geobi_match_ws_bytes(int64_t N);
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+/* geobi_match_coarsen: the integer front end of one pooling step (code/net_util.py:127-128 plus the inverse
+ * lists the feature pooling needs) in one call: the rounds of geobi_match_heavy_edge, then dense ids and
+ * segment lists of the matching -- the results of geobi_relabel_compact and geobi_segment_csr_pairs, with
+ * 6 launches fewer.  state [N]: resumable (-1 undecided, u singleton, v partner); cluster_final [N]: graclus
+ * ids (min member; undecided nodes closed as singletons); cnew [N]; segptr [N+1], members [N] (sized by the
+ * fine node count); counters[0] = undecided nodes, counters[1] = coarse node count (device int32).        */
+size_t geobi_match_coarsen_ws_bytes(int64_t N);
+int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
+                        int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
+                        int32_t* counters, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_relabel_ws_bytes(int64_t N);
 int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count,
                           void* ws, size_t ws_bytes, void* stream);

@@ -491,3 +491,29 @@ def test_feast_split_input_equals_concatenated_at_scale(dev):
     assert rel_err(torch.cat([h1.grad, h2.grad], 1), xa.grad) < 1e-6
     for k, p in conv.named_parameters():
         assert rel_err(p.grad, ref[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('n,m', [(700, 2500), (12000, 40000), (300000, 900000)])
+def test_match_coarsen_equals_separate_calls(dev, n, m):
+    """geobi_match_coarsen = geobi_match_heavy_edge + geobi_relabel_compact + geobi_segment_csr_pairs
+    (the last size runs the two-pass scans instead of the single-launch dual scan)."""
+    from geobi_gnn_amd.graph import Graph
+    from geobi_gnn_amd import net_util, ops
+    ei = _sym_graph(n, m, seed=n + 1, loops=False)
+    g = torch.Generator().manual_seed(n)
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    _, inv = torch.unique(lo * n + hi, return_inverse=True)
+    w = torch.rand(int(inv.max()) + 1, generator=g)[inv]
+    gr = Graph.from_edge_index(ei.to(dev), n)
+    ws = gr.weights_sorted(w.to(dev))
+    for rounds in (2, 8):                                   # 2 rounds leave undecided nodes behind
+        cluster, status, _ = net_util.hip_match(gr, ws, rounds=rounds)
+        cnew, count = net_util.relabel(cluster)
+        ref = ops.SegmentIndex.from_matching(cnew, cluster, n)
+        counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        cl2, cnew2, sidx, _ = net_util.hip_match_coarsen(gr, ws, counters, rounds=rounds)
+        und, nc = counters[:2].tolist()
+        assert und == int(status.item()) and nc == int(count.item())
+        assert torch.equal(cl2, cluster) and torch.equal(cnew2, cnew)
+        assert torch.equal(sidx.segptr[:nc + 1], ref.segptr[:nc + 1])
+        assert torch.equal(sidx.members, ref.members)
