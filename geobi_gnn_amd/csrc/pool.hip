@@ -82,28 +82,42 @@ __device__ __forceinline__ bool edge_better(float w1, int a1, int b1, float w2, 
 // not have been committed yet by w's own thread -- both views agree), so no second "resolve" launch
 // and no grid-wide barrier is needed between the two halves of a round.
 //   prop == -2 : no proposal information (before round 0)      prop == -1 : no free neighbour
+// FIRST != 0: round 0 of a call -- every proposal is "no information" (-2) and, when the call starts from
+// scratch (FIRST == 1), every node is undecided: nothing is read for it, and the round initialises the state
+// itself (no separate init launch).
+template <int FIRST>
 __device__ __forceinline__ bool match_is_free(int w, const int* __restrict__ cluster,
                                               const int* __restrict__ prop_prev) {
+  if (FIRST == 1) return true;
   if (cluster[w] >= 0) return false;
+  if (FIRST == 2) return true;
   int pw = prop_prev[w];
   if (pw == -1) return false;                       // closed as a singleton by the previous round
   return !(pw >= 0 && prop_prev[pw] == w);          // mutually matched in the previous round
 }
 
+template <int FIRST>
 __global__ void match_round_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                    const float* __restrict__ w, const int* __restrict__ prop_prev, int N,
-                                   int* __restrict__ cluster, int* __restrict__ prop_next) {
+                                   int* __restrict__ cluster, int* __restrict__ prop_next, int* __restrict__ status) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (FIRST != 0 && u == 0) *status = 0;
   if (u >= N) return;
-  if (cluster[u] >= 0) { prop_next[u] = -1; return; }
-  int pv = prop_prev[u];
-  if (pv == -1) { cluster[u] = u; prop_next[u] = -1; return; }
-  if (pv >= 0 && prop_prev[pv] == u) { cluster[u] = pv; prop_next[u] = -1; return; }    // state = partner
+  if (FIRST == 1) {
+    cluster[u] = -1;
+  } else {
+    if (cluster[u] >= 0) { prop_next[u] = -1; return; }
+    if (FIRST == 0) {
+      int pv = prop_prev[u];
+      if (pv == -1) { cluster[u] = u; prop_next[u] = -1; return; }
+      if (pv >= 0 && prop_prev[pv] == u) { cluster[u] = pv; prop_next[u] = -1; return; }    // state = partner
+    }
+  }
   int best = -1, ba = 0, bb = 0;
   float bw = 0.f;
   for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
     int v = col[e];
-    if (v == u || !match_is_free(v, cluster, prop_prev)) continue;
+    if (v == u || !match_is_free<FIRST>(v, cluster, prop_prev)) continue;
     float we = w ? w[e] : 1.0f;
     int a = u < v ? u : v, b = u < v ? v : u;
     if (best < 0 || edge_better(we, a, b, bw, ba, bb)) { best = v; bw = we; ba = a; bb = b; }
@@ -162,15 +176,6 @@ __global__ void match_lists_kernel(const int* __restrict__ state, const int* __r
     *count = nc;
     segptr[nc] = N;
   }
-}
-
-__global__ void match_init_kernel(int N, int init, int* __restrict__ cluster, int* __restrict__ prop,
-                                  int* __restrict__ status) {
-  int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u == 0) *status = 0;
-  if (u >= N) return;
-  if (init) cluster[u] = -1;
-  prop[u] = -2;                                     // "no proposal information"
 }
 
 __global__ void match_finish_kernel(int N, const int* __restrict__ state, int* __restrict__ cluster) {
@@ -664,6 +669,22 @@ int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s)
   return 0;
 }
 
+// `rounds` proposal rounds; the first one initialises the state (init != 0) and the undecided counter.
+// On return pp holds the proposals of the last round.
+static void launch_match_rounds(const int32_t* rowptr, const int32_t* col, const float* w, int N, int rounds, int init,
+                                int32_t* cluster, int32_t* status, int*& pp, int*& pn, hipStream_t s) {
+  const int blocks = cdiv(N, 256);
+  for (int r = 0; r < rounds; ++r) {
+    if (r > 0)
+      match_round_kernel<0><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
+    else if (init)
+      match_round_kernel<1><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
+    else
+      match_round_kernel<2><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
+    int* t = pp; pp = pn; pn = t;
+  }
+}
+
 size_t match_ws_bytes(int64_t N) { return 2 * align_up((size_t)N * sizeof(int)) + 1024; }
 
 // Runs `rounds` proposal rounds.  init != 0 starts from scratch, init == 0 continues from the state
@@ -679,13 +700,9 @@ int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, 
   int* prop1 = a.take<int>(N);
   GEOBI_REQUIRE(a.ok() && prop0, "match: workspace too small");
   int blocks = cdiv(N, 256);
-  match_init_kernel<<<blocks, 256, 0, s>>>((int)N, init, cluster, prop0, status);
   int* pp = prop0;
   int* pn = prop1;
-  for (int r = 0; r < rounds; ++r) {
-    match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, cluster, pn);
-    int* t = pp; pp = pn; pn = t;
-  }
+  launch_match_rounds(rowptr, col, w, (int)N, rounds, init, cluster, status, pp, pn, s);
   match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status, cluster_final, nullptr, nullptr);
   GEOBI_LAUNCH_OK();
   return 0;
@@ -714,13 +731,9 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
   void* temp_b = a.take<char>(tb);
   GEOBI_REQUIRE(a.ok() && prop0, "match_coarsen: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int blocks = cdiv(N, 256);
-  match_init_kernel<<<blocks, 256, 0, s>>>((int)N, init, state, prop0, counters);
   int* pp = prop0;
   int* pn = prop1;
-  for (int r = 0; r < rounds; ++r) {
-    match_round_kernel<<<blocks, 256, 0, s>>>(rowptr, col, w, pp, (int)N, state, pn);
-    int* t = pp; pp = pn; pn = t;
-  }
+  launch_match_rounds(rowptr, col, w, (int)N, rounds, init, state, counters, pp, pn, s);
   match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
   GEOBI_LAUNCH_OK();
   if (N + 1 <= 16384) {          // one chunk of the walk: both scans in one launch
