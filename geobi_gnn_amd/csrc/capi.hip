@@ -127,7 +127,7 @@ int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, in
 
 int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* pos_rev, int32_t* flag, void* stream) {
-  NOTNULL(rowptr); NOTNULL(flag);
+  NOTNULL(rowptr);                         // flag may be NULL: the caller knows the graph is symmetric
   if (E > 0) { NOTNULL(row); NOTNULL(col); NOTNULL(pos_rev); }
   return csr_reverse_index(rowptr, row, col, E, pos_rev, flag, S(stream));
 }

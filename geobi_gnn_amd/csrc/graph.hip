@@ -105,7 +105,7 @@ __global__ void reverse_index_kernel(const int32_t* __restrict__ rowptr, const i
     pos_rev[e] = lo;
   } else {
     pos_rev[e] = -1;
-    atomicOr(flag, 1);
+    if (flag) atomicOr(flag, 1);
   }
 }
 
@@ -169,7 +169,7 @@ int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, i
 
 int csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E, int32_t* pos_rev,
                       int32_t* flag, hipStream_t s) {
-  GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+  if (flag != nullptr) GEOBI_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
   if (E <= 0) return 0;
   reverse_index_kernel<<<cdiv(E, 256), 256, 0, s>>>(rowptr, row, col, E, pos_rev, flag);
   GEOBI_LAUNCH_OK();

@@ -55,10 +55,11 @@ class Graph(object):
         g._check_symmetric()
         return g
 
-    def _reverse_index(self):
+    def _reverse_index(self, check=True):
+        """pos[e] = position of the reverse of out-edge e; flag (check=True) != 0 if some edge has none."""
         dev = self.device
         pos = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)[:self.E]
-        flag = torch.empty(1, dtype=torch.int32, device=dev)       # zeroed by the call
+        flag = torch.empty(1, dtype=torch.int32, device=dev) if check else None       # zeroed by the call
         L.call('geobi_csr_reverse_index', L.ptr(self.rowptr_out), L.ptr(self.ensure_rows()), L.ptr(self.col_out),
                self.E, L.ptr(pos), L.ptr(flag), L.stream())
         return pos, flag
@@ -94,7 +95,7 @@ class Graph(object):
             b = self._base.ensure_in()
             self.rowptr_in, self.col_in, self.pos_in = b.rowptr_in, b.col_in, b.pos_in
         if self.rowptr_in is None and self.symmetric:
-            pos, _ = self._reverse_index()
+            pos, _ = self._reverse_index(check=False)      # symmetry is inherited: no flag, no memset
             self.rowptr_in, self.col_in, self.pos_in = self.rowptr_out, self.col_out, pos
         if self.rowptr_in is None:
             dev = self.device

@@ -50,7 +50,8 @@ int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_
 int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                         int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream);
 /* geobi_csr_reverse_index: for a (row, col)-sorted CSR, pos_rev[e] = position of the reverse of edge e
- * (or -1, with flag[0] |= 1, when it is missing).  For a symmetric graph (every mesh graph of the
+ * (or -1, with flag[0] |= 1, when it is missing; flag is zeroed first and may be NULL when the caller
+ * already knows the graph is symmetric).  For a symmetric graph (every mesh graph of the
  * path, and every pooled graph derived from one) the transposed CSR equals the CSR and pos_rev is the
  * edge correspondence -- no second sort. */
 int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E,
