@@ -556,7 +556,8 @@ __global__ __launch_bounds__(1024) void small_exclusive_scan_kernel(const int* _
   }
 }
 
-// Two independent exclusive scans in one launch (same walk as above without the prefetch; used for short arrays).
+// Two independent exclusive scans in one launch: the walk of small_exclusive_scan_kernel over two arrays
+// (16 ints per thread, array and step; the next step's loads in flight while this one is scanned).
 __global__ __launch_bounds__(1024) void small_exclusive_scan2_kernel(const int* __restrict__ in_a,
                                                                      const int* __restrict__ in_b,
                                                                      int* __restrict__ out_a, int* __restrict__ out_b,
@@ -564,18 +565,49 @@ __global__ __launch_bounds__(1024) void small_exclusive_scan2_kernel(const int* 
   constexpr int EPT = 16, CHUNK = 1024 * EPT;
   __shared__ int wsum[2][2][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int carry_a = 0, carry_b = 0, buf = 0;
-  for (int64_t base = 0; base < n; base += CHUNK, buf ^= 1) {
+  const bool vec = ((((uintptr_t)in_a) | ((uintptr_t)in_b) | ((uintptr_t)out_a) | ((uintptr_t)out_b)) & 15) == 0;
+  int ca[EPT], cb[EPT], na[EPT], nb[EPT];
+  auto load = [&](const int* __restrict__ in, int64_t base, int* v) {
     const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
-    int va[EPT], vb[EPT], ta = 0, tb = 0;
+    if (vec && i0 + EPT <= n) {
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const bool ok = i0 + q < n;
-      va[q] = ok ? in_a[i0 + q] : 0;
-      vb[q] = ok ? in_b[i0 + q] : 0;
-      ta += va[q];
-      tb += vb[q];
+      for (int q = 0; q < EPT / 4; ++q) {
+        int4 t = *reinterpret_cast<const int4*>(in + i0 + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) v[q] = (i0 + q < n) ? in[i0 + q] : 0;
     }
+  };
+  auto store = [&](int* __restrict__ out, int64_t base, const int* v, int ex) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+    if (vec && i0 + EPT <= n) {
+#pragma unroll
+      for (int q = 0; q < EPT / 4; ++q) {
+        int4 t;
+        t.x = ex; ex += v[4 * q];
+        t.y = ex; ex += v[4 * q + 1];
+        t.z = ex; ex += v[4 * q + 2];
+        t.w = ex; ex += v[4 * q + 3];
+        *reinterpret_cast<int4*>(out + i0 + 4 * q) = t;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        if (i0 + q < n) out[i0 + q] = ex;
+        ex += v[q];
+      }
+    }
+  };
+  int carry_a = 0, carry_b = 0, buf = 0;
+  load(in_a, 0, ca);
+  load(in_b, 0, cb);
+  for (int64_t base = 0; base < n; base += CHUNK, buf ^= 1) {
+    if (base + CHUNK < n) { load(in_a, base + CHUNK, na); load(in_b, base + CHUNK, nb); }
+    int ta = 0, tb = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) { ta += ca[q]; tb += cb[q]; }
     int ia = ta, ib = tb;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -591,13 +623,11 @@ __global__ __launch_bounds__(1024) void small_exclusive_scan2_kernel(const int* 
       woa += w < wave ? xa : 0; wob += w < wave ? xb : 0;
       tota += xa; totb += xb;
     }
-    int ea = carry_a + woa + ia - ta, eb = carry_b + wob + ib - tb;
+    store(out_a, base, ca, carry_a + woa + ia - ta);
+    store(out_b, base, cb, carry_b + wob + ib - tb);
     carry_a += tota; carry_b += totb;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      if (i0 + q < n) { out_a[i0 + q] = ea; out_b[i0 + q] = eb; }
-      ea += va[q]; eb += vb[q];
-    }
+    for (int q = 0; q < EPT; ++q) { ca[q] = na[q]; cb[q] = nb[q]; }
   }
 }
 
@@ -736,7 +766,7 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
   launch_match_rounds(rowptr, col, w, (int)N, rounds, init, state, counters, pp, pn, s);
   match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
   GEOBI_LAUNCH_OK();
-  if (N + 1 <= 16384) {          // one chunk of the walk: both scans in one launch
+  if (N + 1 <= kSmallScan) {
     small_exclusive_scan2_kernel<<<1, 1024, 0, s>>>(flag, sz, rank, offs, N + 1);
     GEOBI_LAUNCH_OK();
   } else {
