@@ -188,3 +188,39 @@ def load_processed(path, device=None):
     if device is not None:
         dv, df = dv.to(device), df.to(device)
     return dv, df
+
+
+# ------------------------------------------------------------------- augmentation
+class RandomRotate(object):
+    """Training-time augmentation of /root/reference/code/dataset.py:39-69: one random rotation (about z by
+    default, about all three axes with ``z_rotated=False``) applied to the position and normal columns of
+    ``x``, to ``y`` and to ``pos`` / ``centroid`` / ``depth_direction`` of every graph of the pair, in place,
+    on whatever device the tensors live.  ``rng``: optional ``numpy.random.Generator`` (the reference draws
+    from numpy's global state)."""
+
+    def __init__(self, z_rotated=True, rng=None):
+        self.z_rotated = z_rotated
+        self.rng = rng
+
+    def matrix(self):
+        import numpy as np
+        u = self.rng.uniform(size=3) if self.rng is not None else np.random.uniform(size=3)
+        a = u * 2 * np.pi
+        rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+        ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+        return rz if self.z_rotated else rz @ (ry @ rx)
+
+    def __call__(self, data):
+        m = self.matrix()
+        for d in data:
+            r = torch.from_numpy(m).to(dtype=d.x.dtype, device=d.x.device)
+            d.x[:, 0:3] = d.x[:, 0:3] @ r
+            d.x[:, 3:6] = d.x[:, 3:6] @ r
+            if d.y is not None:
+                d.y[:, 0:3] = d.y[:, 0:3] @ r
+            for k in ('pos', 'centroid', 'depth_direction'):
+                v = getattr(d, k, None)
+                if torch.is_tensor(v):
+                    setattr(d, k, v @ r)
+        return data

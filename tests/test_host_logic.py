@@ -290,3 +290,25 @@ def test_processed_file_round_trip(tmp_path):
             else:
                 assert va == vb, k
     assert lv.num_nodes == dv.num_nodes and lf.fv_indices.dtype == torch.int64
+
+
+def test_random_rotate_is_a_rigid_motion_of_both_graphs():
+    """dataset.py:39-69: positions, normals and targets of both graphs turn by the same rotation."""
+    from geobi_gnn_amd import meshgen
+    from geobi_gnn_amd.data import RandomRotate
+    dv, df = meshgen.synthetic_dual_data(3, 0.2, seed=4)
+    ref = (dv.clone(), df.clone())
+    for z_only in (True, False):
+        dv, df = ref[0].clone(), ref[1].clone()
+        rot = RandomRotate(z_rotated=z_only, rng=np.random.default_rng(5))
+        m = torch.from_numpy(RandomRotate(z_rotated=z_only, rng=np.random.default_rng(5)).matrix()).float()
+        assert torch.allclose(m @ m.t(), torch.eye(3), atol=1e-6) and abs(float(torch.det(m)) - 1) < 1e-6
+        rot((dv, df))
+        for a, b in ((dv, ref[0]), (df, ref[1])):
+            assert torch.allclose(a.x[:, :3], b.x[:, :3] @ m, atol=1e-5)
+            assert torch.allclose(a.x[:, 3:6], b.x[:, 3:6] @ m, atol=1e-6)
+            assert torch.allclose(a.y, b.y @ m, atol=1e-5)
+        # lengths and normal lengths are preserved; z-only rotations keep z
+        assert torch.allclose(dv.x[:, :3].norm(dim=1), ref[0].x[:, :3].norm(dim=1), atol=1e-4)
+        if z_only:
+            assert torch.allclose(dv.x[:, 2], ref[0].x[:, 2], atol=1e-6)

@@ -21,7 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geobi_gnn_amd import network, meshgen          # noqa: E402
-from geobi_gnn_amd.data import union_batch           # noqa: E402
+from geobi_gnn_amd.data import union_batch, RandomRotate   # noqa: E402
 from geobi_gnn_amd.parallel import (init_distributed, FlatParameters, shard_indices, batched_losses,   # noqa: E402
                                     reduce_sums)
 
@@ -43,6 +43,7 @@ def parse_arguments():
     p.add_argument('--lr_step', type=int, default=50)
     p.add_argument('--lr_decay', type=float, default=0.5)
     p.add_argument('--optimizer', type=str, default='adam', choices=['adam', 'sgd', 'rmsprop'])
+    p.add_argument('--rotate', type=int, default=0, help='1: random z rotation per batch, 2: full 3-axis (dataset.py:39-69)')
     p.add_argument('--seed', type=int, default=40938661)
     p.add_argument('--out', type=str, default='')
     return p.parse_args()
@@ -76,6 +77,8 @@ def main():
     else:
         sch = None
 
+    import numpy as np
+    rotate = None if not opt.rotate else RandomRotate(z_rotated=opt.rotate == 1, rng=np.random.default_rng(opt.seed + rank))
     best, history = math.inf, []
     for epoch in range(1, opt.max_epoch + 1):
         net.train()
@@ -84,6 +87,8 @@ def main():
         for s in range(0, len(mine), opt.batch_size):
             dv, df = union_batch([train[i] for i in mine[s:s + opt.batch_size]])
             dv, df = dv.to(device), df.to(device)
+            if rotate is not None:
+                rotate((dv, df))
             flat.bucket.zero()
             vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
             lv, ln = batched_losses(vp, npred, dv, df, opt.loss_v, opt.loss_n)
