@@ -128,6 +128,14 @@ def call(name, *args):
         check(1, name)
 
 
+def read_i32(t, n=None):
+    """Device int32 tensor -> list of Python ints through geobi_read_i32 (spinning wait on a pinned copy)."""
+    n = t.numel() if n is None else n
+    buf = (ctypes.c_int32 * n)()
+    call('geobi_read_i32', ptr(t), n, buf, stream())
+    return list(buf)
+
+
 _size_cache = {}
 
 

@@ -118,6 +118,12 @@ def _pool_edge_rows(cnew32, sidx, graph, weight_sorted, ncount, count, overflow)
 
 
 _FUSED_COARSEN = os.environ.get('GEOBI_FUSED_COARSEN', '1') == '1'
+# GEOBI_SPIN_READ=0: read the pooling sizes with Tensor.tolist() (blocking copy) instead of geobi_read_i32
+_SPIN_READ = os.environ.get('GEOBI_SPIN_READ', '1') == '1'
+
+
+def _read4(counters):
+    return L.read_i32(counters, 4) if _SPIN_READ else counters.tolist()
 
 
 class _CounterPool(object):
@@ -160,7 +166,7 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
             total += rounds
             rowptr_c, row_c, col_c, w_c = _pool_edge_rows(cnew, sidx, graph, weight_sorted, counters[1:2],
                                                           counters[2:3], counters[3:4])
-            undecided, nc, ec, overflow = counters.tolist()
+            undecided, nc, ec, overflow = _read4(counters)
             if overflow:     # a coarse node gathers > 64 fine entries: take the radix-sort path
                 count = torch.zeros(1, dtype=torch.int32, device=graph.device)
                 rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=count)
@@ -175,7 +181,7 @@ def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
         counters = _counters.take(graph.device)
         cnew, _ = relabel(cluster32, count=counters[1:2])
         rowptr_c, row_c, col_c, w_c, _ = _pool_edge_raw(cnew, graph, weight_sorted, count=counters[2:3])
-        _, nc, ec, _ = counters.tolist()
+        _, nc, ec, _ = _read4(counters)
     coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec], symmetric=graph.symmetric)
     return cnew, coarse, (None if w_c is None else w_c[:ec]), cluster32, sidx
 

@@ -285,6 +285,13 @@ size_t geobi_gemm_tn_ws_bytes(int I, int J, int64_t M);
 int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, float* C, int ldc,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- size read-back ------------
+ * The ONE entry point that waits for the device: copies n (<= 64) int32 from device memory to `host`
+ * after everything enqueued on `stream`, polling (not sleeping) until the copy has landed.  Used for the
+ * data-dependent sizes of a pooling step (coarse node / edge counts; the reference's `unique` /
+ * `numel() == 0` syncs, code/net_util.py:128,139).                                                  */
+int geobi_read_i32(const int32_t* dev, int n, int32_t* host, void* stream);
+
 /* ---------------------------------------------------------------- concurrency --------------
  * Weight-gradient GEMMs are off the critical path of a backward call; by default they run on a
  * library-owned non-blocking HIP stream, forked from and joined back into `stream` INSIDE the call
