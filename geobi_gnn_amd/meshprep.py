@@ -45,7 +45,7 @@ def vf_padded(rowptr, lst, num_vertices):
     dev = rowptr.device
     m = torch.zeros(1, dtype=torch.int32, device=dev)
     L.call('geobi_max_degree', L.ptr(rowptr), int(num_vertices), L.ptr(m), L.stream())
-    maxval = max(int(m.item()), 1)
+    maxval = max(L.read_i32(m, 1)[0], 1)
     vf = torch.empty((int(num_vertices), maxval), dtype=torch.int32, device=dev)
     L.call('geobi_vf_padded', L.ptr(rowptr), L.ptr(lst), int(num_vertices), maxval, L.ptr(vf), L.stream())
     return vf.long()
@@ -71,7 +71,7 @@ def ring_graph(kind, faces, rowptr, lst, num_nodes):
     ws = L.workspace(L.size_query('geobi_ring_graph_ws_bytes', n), dev)
     L.call('geobi_ring_graph_count', kind, L.ptr(faces), L.ptr(rowptr), L.ptr(lst), n, L.ptr(rp), L.ptr(ws),
            ws.numel(), L.stream())
-    E = int(rp[n].item())                                   # one host read per graph (sizes the column array)
+    E = L.read_i32(rp[n:n + 1], 1)[0]                       # one host read per graph (sizes the column array)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
     L.call('geobi_ring_graph_fill', kind, L.ptr(faces), L.ptr(rowptr), L.ptr(lst), n, L.ptr(rp), L.ptr(col),
            L.stream())

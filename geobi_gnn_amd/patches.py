@@ -42,7 +42,7 @@ def submesh(fv, sel, num_vertices):
     ws = L.workspace(L.size_query('geobi_submesh_ws_bytes', n, V), dev)
     L.call('geobi_submesh', L.ptr(fv), L.ptr(sel), n, V, L.ptr(v_idx), L.ptr(f_sub), L.ptr(count), L.ptr(ws),
            ws.numel(), L.stream())
-    return v_idx[:int(count.item())], f_sub
+    return v_idx[:L.read_i32(count, 1)[0]], f_sub
 
 
 def split_patches(points, fv, submesh_size, incidence=None):
