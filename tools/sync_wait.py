@@ -10,16 +10,17 @@ freq = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 torch.manual_seed(0)
 net = network.DualGNN().to(dev)
 flat = FlatParameters(net)
-opt = torch.optim.Adam(flat.parameters(), lr=1e-3)
+opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=True)
 dv, df, edges = bench.make_batch(0, dev, freq)
 for _ in range(5):
     bench.train_step(net, flat.bucket, opt, dv, df)
 torch.cuda.synchronize()
-orig = torch.Tensor.tolist
+from geobi_gnn_amd import _lib as L
+orig = L.read_i32
 wait = [0.0, 0]
-def timed(self):
-    t0 = time.perf_counter(); r = orig(self); wait[0] += time.perf_counter() - t0; wait[1] += 1; return r
-torch.Tensor.tolist = timed
+def timed(t, n=None):
+    t0 = time.perf_counter(); r = orig(t, n); wait[0] += time.perf_counter() - t0; wait[1] += 1; return r
+L.read_i32 = timed
 R = 30
 t0 = time.perf_counter()
 for _ in range(R):
