@@ -112,10 +112,11 @@ const char* geobi_last_error(void) { return g_err; }
 size_t geobi_csr_ws_bytes(int64_t E, int64_t N) { return csr_ws_bytes(E, N); }
 
 int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self,
-                       int32_t* rowptr, int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, void* stream) {
+                       int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* bad, void* ws, size_t ws_bytes,
+                       void* stream) {
   NOTNULL(rowptr);
   if (E > 0) { NOTNULL(seg); NOTNULL(nbr); NOTNULL(col); NOTNULL(eid); }
-  return csr_from_coo(seg, nbr, E, N, drop_self, rowptr, col, eid, ws, ws_bytes, S(stream));
+  return csr_from_coo(seg, nbr, E, N, drop_self, rowptr, col, eid, bad, ws, ws_bytes, S(stream));
 }
 
 int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,

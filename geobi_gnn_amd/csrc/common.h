@@ -66,7 +66,7 @@ int side_wait_main(const Fork& f, hipStream_t main);     // side stream waits fo
 // graph.hip
 size_t csr_ws_bytes(int64_t E, int64_t N);
 int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self, int32_t* rowptr,
-                 int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, hipStream_t s);
+                 int32_t* col, int32_t* eid, int32_t* bad, void* ws, size_t ws_bytes, hipStream_t s);
 int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                   int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, hipStream_t s);
 int csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E, int32_t* pos_rev,

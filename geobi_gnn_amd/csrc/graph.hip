@@ -29,11 +29,14 @@ static inline int key_bits(int64_t N) {
 }
 
 __global__ void make_keys_kernel(const int64_t* __restrict__ seg, const int64_t* __restrict__ nbr, int64_t E,
-                                 int drop_self, int bits, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                 int64_t N, int drop_self, int bits, uint64_t* __restrict__ keys,
+                                 int32_t* __restrict__ vals, int32_t* __restrict__ bad) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t a = seg[e], b = nbr[e];
-  keys[e] = (drop_self && a == b) ? kSentinel : (((uint64_t)a << bits) | (uint64_t)(uint32_t)b);
+  const bool ok = a >= 0 && a < N && b >= 0 && b < N;       // ids outside [0, N) never reach the kernels
+  if (!ok && bad != nullptr) atomicAdd(bad, 1);
+  keys[e] = (!ok || (drop_self && a == b)) ? kSentinel : (((uint64_t)a << bits) | (uint64_t)(uint32_t)b);
   vals[e] = (int32_t)e;
 }
 
@@ -143,8 +146,9 @@ size_t csr_ws_bytes(int64_t E, int64_t N) {
 }
 
 int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self, int32_t* rowptr,
-                 int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, hipStream_t s) {
+                 int32_t* col, int32_t* eid, int32_t* bad, void* ws, size_t ws_bytes, hipStream_t s) {
   GEOBI_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "csr_from_coo: sizes out of int32 range");
+  if (bad != nullptr) GEOBI_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), s));
   if (E == 0) {
     GEOBI_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (N + 1), s));
     return 0;
@@ -155,7 +159,7 @@ int csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, i
   GEOBI_REQUIRE(a.ok() && ws != nullptr, "csr_from_coo: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int T = 256;
   const int bits = key_bits(N);
-  make_keys_kernel<<<cdiv(E, T), T, 0, s>>>(seg, nbr, E, drop_self, bits, sb.k_in, sb.v_in);
+  make_keys_kernel<<<cdiv(E, T), T, 0, s>>>(seg, nbr, E, N, drop_self, bits, sb.k_in, sb.v_in, bad);
   GEOBI_LAUNCH_OK();
   size_t tb = sb.temp_bytes;
   GEOBI_HIP(rocprim::radix_sort_pairs(sb.temp, tb, sb.k_in, sb.k_out, sb.v_in, eid, (size_t)E, 0u, (unsigned)(2 * bits), s,

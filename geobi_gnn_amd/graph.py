@@ -48,9 +48,13 @@ class Graph(object):
         eid = torch.empty(max(E0, 1), dtype=torch.int32, device=dev)
         nb = L.size_query('geobi_csr_ws_bytes', E0, g.N)
         ws = L.workspace(nb, dev)
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
         L.call('geobi_csr_from_coo', L.ptr(ei[0]), L.ptr(ei[1]), E0, g.N, 1, L.ptr(g.rowptr_out), L.ptr(col),
-               L.ptr(eid), L.ptr(ws), ws.numel(), L.stream())
-        g.E = int(g.rowptr_out[g.N].item())
+               L.ptr(eid), L.ptr(bad), L.ptr(ws), ws.numel(), L.stream())
+        g.E = L.read_i32(g.rowptr_out[g.N:g.N + 1], 1)[0]
+        nbad = L.read_i32(bad, 1)[0]
+        if nbad:
+            raise L.GeobiError('edge_index holds %d entries with node ids outside [0, %d)' % (nbad, g.N))
         g.col_out, g.eid_out = col[:g.E], eid[:g.E]
         g._check_symmetric()
         return g

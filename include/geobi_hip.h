@@ -41,12 +41,14 @@ const char* geobi_last_error(void);
  *
  * geobi_csr_from_coo: sort E (segment, neighbour) int64 pairs by (segment, neighbour); self loops
  * are dropped when drop_self != 0.  rowptr[N] is the number of kept edges; col / eid have E slots
- * (eid[k] = position of sorted edge k in the input COO).
+ * (eid[k] = position of sorted edge k in the input COO).  Pairs with an id outside [0, N) are dropped
+ * and counted in bad[0] (device int32, optional): they never reach a kernel as an index.
  * geobi_csr_transpose: CSR of the reversed edges; pos_t[e'] = index of that edge in the input CSR,
  * inv_pos[e] = index of input edge e in the transposed CSR (either may be NULL... pos_t may not). */
 size_t geobi_csr_ws_bytes(int64_t E, int64_t N);
 int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self,
-                       int32_t* rowptr, int32_t* col, int32_t* eid, void* ws, size_t ws_bytes, void* stream);
+                       int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* bad, void* ws, size_t ws_bytes,
+                       void* stream);
 int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                         int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream);
 /* geobi_csr_reverse_index: for a (row, col)-sorted CSR, pos_rev[e] = position of the reverse of edge e

@@ -389,6 +389,17 @@ def test_errors_are_loud(dev):
         conv(torch.randn(10, 7, device=dev), torch.zeros(2, 4, dtype=torch.long, device=dev))   # wrong width
     with pytest.raises(L.GeobiError):
         L.call('geobi_gemm_nn', None, 1, None, 1, 0, None, 1, 1, 1, 1, None, 1.0, L.stream())
+    # node ids outside [0, N) are caught when the adjacency is built, not by a faulting gather later
+    bad = torch.tensor([[0, 1, 2, 11], [1, 0, 3, 2]], device=dev)
+    with pytest.raises(L.GeobiError, match='outside'):
+        conv(torch.randn(10, 6, device=dev), bad)
+    neg = torch.tensor([[0, 1, -1], [1, 0, 2]], device=dev)
+    with pytest.raises(L.GeobiError, match='outside'):
+        conv(torch.randn(10, 6, device=dev), neg)
+    with pytest.raises(NotImplementedError):
+        FeaStConv(6, 32, 4)
+    with pytest.raises(L.GeobiError):
+        FeaStConv(16, 32, 9).to(dev)(torch.randn(10, 16, device=dev), torch.tensor([[0, 1], [1, 0]], device=dev))
 
 
 def test_symmetric_graph_reverse_index(dev):
