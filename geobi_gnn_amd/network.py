@@ -65,6 +65,10 @@ def _fv_index(data_f, num_vertices):
     cache = getattr(fv, '_geobi_fv', None)
     if cache is None or cache[2] != num_vertices:
         fv32 = fv.to(torch.int32).contiguous()
+        if fv32.numel():        # once per mesh (cached): a bad vertex id would be a faulting gather later
+            lo, hi = torch.aminmax(fv32)
+            if int(lo) < 0 or int(hi) >= num_vertices:
+                raise L.GeobiError('fv_indices index vertices outside [0, %d)' % num_vertices)
         cidx = ops.SegmentIndex(fv32.view(-1), num_vertices)
         cache = (fv32, cidx, num_vertices)
         fv._geobi_fv = cache

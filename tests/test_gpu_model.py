@@ -453,3 +453,16 @@ def test_degenerate_graphs(dev):
         eh = out.edge_index.cpu() if out.edge_index is not None else torch.zeros((2, 0), dtype=torch.long)
         assert eh.shape[1] == ref.edge_index.shape[1], name
         assert torch.equal(layer_h.unpooling(out.x).cpu(), layer_o.unpooling(ref.x)), name
+
+
+def test_bad_face_table_is_rejected(dev):
+    from geobi_gnn_amd import network, meshgen
+    from geobi_gnn_amd._lib import GeobiError
+    dv, df = meshgen.synthetic_dual_data(3, 0.2, seed=1)
+    dv, df = dv.to(dev), df.to(dev)
+    df.fv_indices = df.fv_indices.clone()
+    df.fv_indices[0, 0] = dv.x.shape[0] + 5
+    net = network.DualGNN().to(dev).eval()
+    with pytest.raises(GeobiError, match='fv_indices'):
+        with torch.no_grad():
+            net((dv, df))
