@@ -85,6 +85,23 @@ class Graph(object):
         g.symmetric = symmetric
         return g
 
+    @staticmethod
+    def union(graphs):
+        """Disjoint union of loop-free sorted CSR graphs (node ids of graph k shifted by the node counts before
+        it): the batched form of independent meshes / patches, built without going through COO."""
+        dev = graphs[0].device
+        g = Graph(sum(x.N for x in graphs), dev)
+        rps, cols, noff, eoff = [], [], 0, 0
+        for x in graphs:
+            rps.append(x.rowptr_out[:x.N] + eoff)
+            cols.append(x.col_out + noff)
+            noff += x.N
+            eoff += x.E
+        rps.append(torch.full((1,), eoff, dtype=torch.int32, device=dev))
+        g.rowptr_out, g.col_out, g.E = torch.cat(rps), torch.cat(cols), eoff
+        g.symmetric = all(x.symmetric for x in graphs) if all(x.symmetric is not None for x in graphs) else None
+        return g
+
     def ensure_rows(self):
         if self.row_out is None and self._base is not None:
             self.row_out = self._base.ensure_rows()

@@ -46,6 +46,10 @@ def test_predict_mesh_merges_like_the_reference(dev):
     sub = int(fx['sub_size'])
     out = patches.predict_mesh(net, pts, fv, sub_size=sub, n_iter=5, gt_points=fx['clean'])
     assert out['n_patches'] == len(fx['seeds'])
+    # patches through the network one by one or several per pass (disjoint union): the same numbers
+    for pb in (1, 3):
+        alt = patches.predict_mesh(net, pts, fv, sub_size=sub, n_iter=5, patch_batch=pb)
+        assert torch.equal(alt['Np'], out['Np']) and torch.equal(alt['Vp'], out['Vp'])
 
     rowptr, lst = meshprep.vertex_faces(fv, V)
     g_v = meshprep.ring_graph(0, fv, rowptr, lst, V)

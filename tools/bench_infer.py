@@ -47,17 +47,19 @@ for name, n, reps in (('configs[1] single mesh n=32', 32, 20), ('configs[3] larg
                                      'frac_of_8TBps': round(best[2] / (best[1] * 1e-3) / 1e9 / 8000, 3)}})
 # end to end from the raw mesh (points + faces already in HBM): device preprocessing (graphs, normals,
 # bilateral weights), optional patch split, network, merge, 60-sweep vertex update
-for name, n, sub, reps in (('configs[1] n=32 mesh -> denoised vertices', 32, 20480, 10),
-                           ('configs[3] n=87 mesh -> denoised vertices, unsplit (sub_size=200000)', 87, 200000, 5),
-                           ('configs[3] n=87 mesh -> denoised vertices, split at sub_size=20000', 87, 20000, 3)):
+for name, n, sub, reps, pb in (('configs[1] n=32 mesh -> denoised vertices', 32, 20480, 10, 4),
+                               ('configs[3] n=87 mesh -> denoised vertices, unsplit (sub_size=200000)', 87, 200000, 5, 4),
+                               ('configs[3] n=87 mesh -> denoised vertices, split at sub_size=20000, patches one by one', 87, 20000, 3, 1),
+                               ('configs[3] n=87 mesh -> denoised vertices, split at sub_size=20000, 4 patches per pass', 87, 20000, 3, 4),
+                               ('configs[3] n=87 mesh -> denoised vertices, split at sub_size=20000, 8 patches per pass', 87, 20000, 3, 8)):
     noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed=7)
     pts = torch.from_numpy(noisy).to(dev)
     fv = torch.from_numpy(faces).to(dev).int()
     gt = torch.from_numpy(clean).to(dev)
-    r = patches.predict_mesh(net, pts, fv, sub_size=sub, gt_points=gt)
+    r = patches.predict_mesh(net, pts, fv, sub_size=sub, gt_points=gt, patch_batch=pb)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
-        r = patches.predict_mesh(net, pts, fv, sub_size=sub)
+        r = patches.predict_mesh(net, pts, fv, sub_size=sub, patch_batch=pb)
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / reps
     out.append({'workload': name, 'faces': int(faces.shape[0]), 'patches': r['n_patches'],
                 'end_to_end_ms': round(t * 1e3, 3), 'k_faces_per_s': round(faces.shape[0] / t / 1e3, 1)})
