@@ -146,6 +146,36 @@ def union_batch(dual_list):
     return data_v, data_f
 
 
+def union_batch_graphs(dual_list):
+    """``union_batch`` for device-resident pairs whose adjacency is already built (``Data.graph()``): the CSR
+    graphs are concatenated directly (``Graph.union``) -- no COO round trip, no sort, no host sync -- and edge
+    weights are taken in CSR order.  Same result fields as ``union_batch`` (``edge_index`` materialises
+    lazily, loop-free)."""
+    from .graph import Graph
+    gvs = [dv.graph() for dv, _ in dual_list]
+    gfs = [df.graph() for _, df in dual_list]
+    ptr_v, ptr_f, fv = [0], [0], []
+    for dv, df in dual_list:
+        fv.append(df.fv_indices + ptr_v[-1])
+        ptr_v.append(ptr_v[-1] + dv.x.shape[0])
+        ptr_f.append(ptr_f[-1] + df.x.shape[0])
+
+    def cat(items):
+        return torch.cat(items) if all(t is not None for t in items) else None
+
+    data_v = Data(torch.cat([dv.x for dv, _ in dual_list]), None, y=cat([dv.y for dv, _ in dual_list]),
+                  depth_direction=cat([getattr(dv, 'depth_direction', None) for dv, _ in dual_list]), name='union-v')
+    data_f = Data(torch.cat([df.x for _, df in dual_list]), None, y=cat([df.y for _, df in dual_list]),
+                  fv_indices=torch.cat(fv), name='union-f')
+    data_v.set_graph(Graph.union(gvs))
+    data_f.set_graph(Graph.union(gfs))
+    data_v.edge_weight = torch.cat([g.weights_sorted(dv.edge_weight) for g, (dv, _) in zip(gvs, dual_list)])
+    data_f.edge_weight = torch.cat([g.weights_sorted(df.edge_weight) for g, (_, df) in zip(gfs, dual_list)])
+    data_v.mesh_ptr = torch.tensor(ptr_v, dtype=torch.long)
+    data_f.mesh_ptr = torch.tensor(ptr_f, dtype=torch.long)
+    return data_v, data_f
+
+
 # ------------------------------------------------------------------- processed-file cache
 # The reference caches every preprocessed (sub)mesh as ``torch.save((data_v, data_f), name.pt)`` of pickled
 # PyG ``Data`` objects (/root/reference/code/dataset.py:153,182; read back at :276).  Unpickling needs PyG and

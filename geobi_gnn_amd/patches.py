@@ -72,23 +72,10 @@ def split_patches(points, fv, submesh_size, incidence=None):
 def _union_dual(duals):
     """Several device-built (data_v, data_f) pairs -> one pair over the disjoint union of their graphs (CSR
     concatenated directly); returns the pair and the per-patch (vertex, face) row ranges."""
-    from .data import Data
-    from .graph import Graph
-    gv = Graph.union([d[0].graph() for d in duals])
-    gf = Graph.union([d[1].graph() for d in duals])
-    voff, vr, fr, fvs, fo = 0, [], [], [], 0
-    for dv, df in duals:
-        nv, nf = dv.x.shape[0], df.x.shape[0]
-        vr.append((voff, voff + nv)); fr.append((fo, fo + nf))
-        fvs.append(df.fv_indices + voff)
-        voff += nv; fo += nf
-    data_v = Data(torch.cat([d[0].x for d in duals]), None, name='patches-v')
-    data_f = Data(torch.cat([d[1].x for d in duals]), None, fv_indices=torch.cat(fvs), name='patches-f')
-    data_v.set_graph(gv); data_v.edge_weight = torch.cat([d[0].edge_weight for d in duals])
-    data_f.set_graph(gf); data_f.edge_weight = torch.cat([d[1].edge_weight for d in duals])
-    dds = [getattr(d[0], 'depth_direction', None) for d in duals]
-    data_v.depth_direction = torch.cat(dds) if all(t is not None for t in dds) else None
-    return (data_v, data_f), vr, fr
+    from .data import union_batch_graphs
+    data_v, data_f = union_batch_graphs(duals)
+    pv, pf = data_v.mesh_ptr.tolist(), data_f.mesh_ptr.tolist()
+    return (data_v, data_f), list(zip(pv[:-1], pv[1:])), list(zip(pf[:-1], pf[1:]))
 
 
 def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=8):

@@ -466,3 +466,31 @@ def test_bad_face_table_is_rejected(dev):
     with pytest.raises(GeobiError, match='fv_indices'):
         with torch.no_grad():
             net((dv, df))
+
+
+def test_union_of_prebuilt_graphs_equals_coo_union(dev):
+    """union_batch_graphs (CSR concatenation on the device) gives the network the same batch as union_batch
+    (COO concatenation + CSR build): identical adjacency, weights, outputs and per-mesh losses."""
+    from geobi_gnn_amd import network, meshgen
+    from geobi_gnn_amd.data import union_batch, union_batch_graphs
+    from geobi_gnn_amd.parallel import batched_losses
+    duals = [meshgen.synthetic_dual_data(n, 0.2, seed=30 + n) for n in (5, 9, 3)]
+    cv, cf = union_batch(duals)
+    cv, cf = cv.to(dev), cf.to(dev)
+    on_dev = [(a.to(dev), b.to(dev)) for a, b in duals]
+    gv, gf = union_batch_graphs(on_dev)
+    for a, b in ((cv, gv), (cf, gf)):
+        ga, gb = a.graph(), b.graph()
+        assert torch.equal(ga.rowptr_out, gb.rowptr_out) and torch.equal(ga.col_out, gb.col_out)
+        assert torch.equal(ga.weights_sorted(a.edge_weight), b.edge_weight)
+        assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y)
+    assert torch.equal(cf.fv_indices, gf.fv_indices) and torch.equal(cv.mesh_ptr.cpu(), gv.mesh_ptr.cpu())
+    torch.manual_seed(1)
+    net = network.DualGNN().to(dev).eval()
+    with torch.no_grad():
+        v0, n0, _ = net((cv.shallow_copy(), cf.shallow_copy()))
+        v1, n1, _ = net((gv.shallow_copy(), gf.shallow_copy()))
+    assert torch.equal(v0, v1) and torch.equal(n0, n1)
+    l0 = batched_losses(v0, n0, cv, cf, 'L1', 'L1')
+    l1 = batched_losses(v1, n1, gv, gf, 'L1', 'L1')
+    assert float(l0[0]) == float(l1[0]) and float(l0[1]) == float(l1[1])

@@ -21,7 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geobi_gnn_amd import network, meshgen          # noqa: E402
-from geobi_gnn_amd.data import union_batch, RandomRotate   # noqa: E402
+from geobi_gnn_amd.data import union_batch_graphs, RandomRotate   # noqa: E402
 from geobi_gnn_amd.parallel import (init_distributed, FlatParameters, shard_indices, batched_losses,   # noqa: E402
                                     reduce_sums)
 
@@ -58,6 +58,10 @@ def main():
     train = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=1000 + i) for i in range(opt.n_train)]
     evals = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=5000 + i) for i in range(opt.n_eval)]
     evals = [(a.to(device), b.to(device)) for a, b in evals]
+    # training meshes live on the device with their adjacency built once; a step's batch is a CSR concatenation
+    train = [(a.to(device), b.to(device)) for a, b in train]
+    for a, b in train:
+        a.graph(); b.graph()
 
     net = network.DualGNN(force_depth=False, pool_type='max', wei_param=opt.wei_param).to(device)
     flat = FlatParameters(net)
@@ -85,8 +89,7 @@ def main():
         mine = shard_indices(len(train), rank, world, seed=opt.seed, epoch=epoch)
         t0 = time.time()
         for s in range(0, len(mine), opt.batch_size):
-            dv, df = union_batch([train[i] for i in mine[s:s + opt.batch_size]])
-            dv, df = dv.to(device), df.to(device)
+            dv, df = union_batch_graphs([train[i] for i in mine[s:s + opt.batch_size]])
             if rotate is not None:
                 rotate((dv, df))
             flat.bucket.zero()
