@@ -118,8 +118,15 @@ def _mesh_weights(data):
         return None
     w = getattr(data, '_loss_weights', None)
     if w is None or w.device != data.y.device:
+        dev = data.y.device
         counts = ptr[1:] - ptr[:-1]
-        w = torch.repeat_interleave(1.0 / (counts.float() * counts.numel()), counts).to(data.y.device)
+        per_mesh = (1.0 / (counts.float() * counts.numel())).to(dev)
+        if dev.type == 'cuda' and not ptr.is_cuda:
+            # expand on the device (two small kernels) instead of on the host + a copy of N floats
+            seg = torch.bucketize(torch.arange(int(ptr[-1]), device=dev), ptr[1:].to(dev), right=True)
+            w = per_mesh[seg]
+        else:
+            w = torch.repeat_interleave(per_mesh, counts.to(dev))
         data._loss_weights = w
     return w
 
