@@ -10,7 +10,7 @@ freq = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 torch.manual_seed(0)
 net = network.DualGNN().to(dev)
 flat = FlatParameters(net)
-opt = torch.optim.Adam(flat.parameters(), lr=1e-3)
+opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=True)
 dv, df, edges = bench.make_batch(0, dev, freq)
 for _ in range(5):
     bench.train_step(net, flat.bucket, opt, dv, df)
