@@ -9,7 +9,9 @@
  * Conventions
  *   - every pointer is a BORROWED device pointer (HBM) unless marked `host`; the library never
  *     allocates, frees or synchronises: scratch comes in through `ws` / `ws_bytes` (query the size
- *     with the matching *_ws_bytes function, which is a pure host computation + rocPRIM size query)
+ *     with the matching *_ws_bytes function, which is a pure host computation + rocPRIM size query).
+ *     Two documented exceptions: geobi_read_i32 (the size read-back: waits for `stream`) and
+ *     geobi_patch_grow_host (an ordered traversal over HOST arrays)
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
  *   - return value 0 = ok, non-zero = error; the message is in geobi_last_error() (thread-local)
  *   - node features are row-major fp32; indices inside the library are int32 (max 2^31-1 edges);
