@@ -232,9 +232,13 @@ __global__ void centroid_kernel(const float* __restrict__ pts, const int* __rest
 }
 
 // p_v += 1/max(cnt,1) * sum_{f adj v} n_f (n_f . (c_f - p_v))      (optionally projected on dd_v)
+// cent == nullptr: the centroid of every adjacent face is formed on the fly from the OLD positions (same
+// expression as centroid_kernel, so the same bits) -- one launch per sweep instead of two, which is what the
+// 60-sweep loop is bound by.
 __global__ void vertex_update_kernel(const float* __restrict__ pts, const float* __restrict__ cent,
-                                     const float* __restrict__ nrm, const int* __restrict__ vf, int maxval,
-                                     const float* __restrict__ dd, int V, float* __restrict__ out) {
+                                     const int* __restrict__ fv, const float* __restrict__ nrm,
+                                     const int* __restrict__ vf, int maxval, const float* __restrict__ dd, int V,
+                                     float* __restrict__ out) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   V3 p = ld3(pts + 3 * (size_t)v);
@@ -245,7 +249,15 @@ __global__ void vertex_update_kernel(const float* __restrict__ pts, const float*
     if (f < 0) continue;
     ++cnt;
     V3 n = ld3(nrm + 3 * (size_t)f);
-    float d = dot(n, sub(ld3(cent + 3 * (size_t)f), p));
+    V3 c;
+    if (cent != nullptr) {
+      c = ld3(cent + 3 * (size_t)f);
+    } else {
+      V3 t = add(add(ld3(pts + 3 * (size_t)fv[3 * f]), ld3(pts + 3 * (size_t)fv[3 * f + 1])),
+                 ld3(pts + 3 * (size_t)fv[3 * f + 2]));
+      c.x = t.x / 3.0f; c.y = t.y / 3.0f; c.z = t.z / 3.0f;
+    }
+    float d = dot(n, sub(c, p));
     s = add(s, mul(n, d));
   }
   float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
@@ -296,7 +308,6 @@ int update_position2(const float* points, const int32_t* fv, const int32_t* vf, 
                      hipStream_t s) {
   GEOBI_REQUIRE(V > 0 && F > 0 && n_iter >= 0, "update_position2: empty mesh");
   Arena a(ws, ws_bytes);
-  float* cent = a.take<float>((size_t)F * 3);
   float* tmp = a.take<float>((size_t)V * 3);
   GEOBI_REQUIRE(a.ok() && ws, "update_position2: workspace too small");
   // ping-pong so that the LAST iteration lands in `out`
@@ -307,8 +318,7 @@ int update_position2(const float* points, const int32_t* fv, const int32_t* vf, 
   }
   for (int it = 0; it < n_iter; ++it) {
     float* dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmp;
-    centroid_kernel<<<cdiv(F, 256), 256, 0, s>>>(src, fv, (int)F, cent);
-    vertex_update_kernel<<<cdiv(V, 256), 256, 0, s>>>(src, cent, normals, vf, maxval, dd, (int)V, dst);
+    vertex_update_kernel<<<cdiv(V, 256), 256, 0, s>>>(src, nullptr, fv, normals, vf, maxval, dd, (int)V, dst);
     src = dst;
   }
   GEOBI_LAUNCH_OK();
