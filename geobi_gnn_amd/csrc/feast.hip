@@ -52,6 +52,13 @@ __device__ __forceinline__ void load_hp(const float* __restrict__ row, float (&v
   v[8] = c.x;
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its
+// own L2.  A node's neighbours are mostly nearby nodes, so a contiguous eighth of the node range per XCD
+// keeps every gathered row in ONE L2 instead of eight: launched block b works on virtual block
+// (b % 8) * (grid / 8) + b / 8.  The grid is padded to a multiple of 8; the surplus blocks land beyond N and exit.
+__host__ __device__ __forceinline__ int xcd_grid(int blocks) { return (blocks + 7) / 8 * 8; }
+__device__ __forceinline__ int xcd_block(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
+
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* __restrict__ ptr, float (&v)[VEC]) {
   if constexpr (VEC == 4) {
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / G, k = lane % G;
   float(*slot)[HP] = s_slot[wave];
-  const int node0 = (blockIdx.x * 4 + wave) * NPW;
+  const int node0 = (xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * NPW;
   if (node0 >= N) return;
   const int node = node0 + g;
   const bool valid = node < N;
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void feast_rowpass_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / G, k = lane % G;
   float(*slot)[HP] = s_slot[wave];
-  const int node0 = (blockIdx.x * 4 + wave) * NPW;
+  const int node0 = (xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * NPW;
   if (node0 >= N) return;
   const int node = node0 + g;
   const bool valid = node < N;
@@ -455,7 +462,7 @@ int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const floa
 #define GEOBI_AGG(C_, V_)                                                                                         \
   do {                                                                                                            \
     constexpr int NPW_ = 64 / (C_ / V_);                                                                          \
-    feast_aggregate_kernel<C_, V_, MODE><<<cdiv(N, 4 * NPW_), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col,     \
+    feast_aggregate_kernel<C_, V_, MODE><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col,     \
                                                                             deg_rowptr, N, out, ldo);             \
   } while (0)
   switch (C) {
@@ -477,7 +484,7 @@ int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float*
 #define GEOBI_ROW(C_, V_)                                                                                     \
   do {                                                                                                        \
     constexpr int NPW_ = 64 / (C_ / V_);                                                                      \
-    feast_rowpass_kernel<C_, V_><<<cdiv(N, 4 * NPW_), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
+    feast_rowpass_kernel<C_, V_><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
                                                                    N, dl, dpn, dcs, ld_dcs);                  \
   } while (0)
   switch (C) {
