@@ -233,7 +233,13 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
     float v[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) v[i] = acc[h][i] * scale;
-    store_vec<VEC>(orow + h * C + c0, v);
+    if constexpr (MODE == 0 && VEC == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 t = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(t, reinterpret_cast<f4*>(orow + h * C + c0));   // z is written once, streamed
+    } else {
+      store_vec<VEC>(orow + h * C + c0, v);
+    }
   }
   if constexpr (MODE == 0) {
     // zero the row padding [H*C, ldo) so the packed GEMM can run over the padded K
