@@ -359,9 +359,10 @@ def _edge_map(ei, w, n):
     return key[order], w.detach().cpu()[order]
 
 
-@pytest.mark.parametrize('wtype', [-1, 0, 1, 2, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('wtype', [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_edge_weight_types_match_oracle(dev, wtype):
-    """PoolingLayer._get_edge_weight, every non-learned edge_weight_type (net_util.py:169-230)."""
+    """PoolingLayer._get_edge_weight, every edge_weight_type incl. the learned attention of types 3-5
+    (net_util.py:169-230); the learned parameters are copied from the oracle layer."""
     from geobi_gnn_amd import net_util, meshgen
     from oracle import ref_model as R, pyg_ops as P
     dv, _ = meshgen.synthetic_dual_data(5, 0.2, seed=wtype + 20)
@@ -371,7 +372,9 @@ def test_edge_weight_types_match_oracle(dev, wtype):
     ora = R.PoolingLayer(32, 'max', 2, wtype, wei_param=3)
     do = P.Data(feat.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone())
     w_o = ora._get_edge_weight(do)
-    hip = net_util.PoolingLayer(32, 'max', 2, wtype, wei_param=3).to(dev)
+    hip = net_util.PoolingLayer(32, 'max', 2, wtype, wei_param=3)
+    hip.load_state_dict(ora.state_dict())
+    hip = hip.to(dev)
     dh = dv.to(dev)
     dh.x = feat.to(dev)
     w_h = hip._get_edge_weight(dh)
