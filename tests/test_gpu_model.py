@@ -497,3 +497,36 @@ def test_union_of_prebuilt_graphs_equals_coo_union(dev):
     l0 = batched_losses(v0, n0, cv, cf, 'L1', 'L1')
     l1 = batched_losses(v1, n1, gv, gf, 'L1', 'L1')
     assert float(l0[0]) == float(l1[0]) and float(l0[1]) == float(l1[1])
+
+
+@pytest.mark.parametrize('pool_step,pool_type', [(1, 'max'), (3, 'max'), (3, 'mean')])
+def test_pooling_layer_other_step_counts_against_oracle(dev, pool_step, pool_type):
+    """PoolingLayer with 1 and 3 matching steps (the network uses 2): HIP matching replayed on the oracle layer --
+    pooled features, composed unpool index, coarse edges and weights, and the unpool gradient."""
+    from geobi_gnn_amd import net_util, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    dv, _ = meshgen.synthetic_dual_data(6, 0.2, seed=40 + pool_step)
+    torch.manual_seed(pool_step)
+    feat = torch.randn(dv.x.shape[0], 32)
+    n = feat.shape[0]
+    layer_h = net_util.PoolingLayer(32, pool_type, pool_step, 10).to(dev)
+    dh = dv.to(dev)
+    xh = feat.to(dev).requires_grad_(True)
+    dh.x = xh
+    out = layer_h(dh)
+    assert len(layer_h.last_clusters) == pool_step
+    layer_o = R.PoolingLayer(32, pool_type, pool_step, 10)
+    clusters = iter([c.cpu() for c in layer_h.last_clusters])
+    layer_o.graclus_fn = lambda e, ww=None, nn=None: next(clusters)
+    xo = feat.clone().requires_grad_(True)
+    ref = layer_o(P.Data(xo, dv.edge_index.clone(), edge_weight=dv.edge_weight.clone()))
+    assert rel_err(out.x.detach().cpu(), ref.x.detach()) < 1e-6
+    assert torch.equal(layer_h.unpooling_indices.cpu(), layer_o.unpooling_indices)
+    nc = ref.x.shape[0]
+    kh, wh = _edge_map(out.edge_index, out.edge_weight, nc)
+    ko, wo = _edge_map(ref.edge_index, ref.edge_weight, nc)
+    assert torch.equal(kh, ko) and rel_err(wh, wo.double()) < 1e-5
+    g = torch.randn(n, 32)
+    layer_h.unpooling(out.x).backward(g.to(dev))
+    layer_o.unpooling(ref.x).backward(g)
+    assert rel_err(xh.grad.cpu(), xo.grad) < 1e-6
