@@ -164,7 +164,7 @@ def pmc_traffic(kernel):
         return None, None
 
 
-def cpu_baseline(freq=FREQ, timed=3):
+def cpu_baseline(freq=FREQ, timed=5, warm=2):
     """PyG-shaped oracle, fp32, all host cores, ONE mesh of the bench size (bounded sample)."""
     from geobi_gnn_amd import meshgen
     from oracle import ref_model as R, pyg_ops as P
@@ -175,7 +175,7 @@ def cpu_baseline(freq=FREQ, timed=3):
     torch.manual_seed(0)
     net = R.DualGNN()
     times = []
-    for it in range(1 + timed):
+    for it in range(warm + timed):
         a = P.Data(dv.x.clone(), dv.edge_index, edge_weight=dv.edge_weight, y=dv.y)
         b = P.Data(df.x.clone(), df.edge_index, edge_weight=df.edge_weight, y=df.y, fv_indices=df.fv_indices)
         net.zero_grad()
@@ -185,13 +185,60 @@ def cpu_baseline(freq=FREQ, timed=3):
         loss.backward()
         dt = time.perf_counter() - t0
         log('cpu oracle pass %d: %.2f s on %d threads' % (it, dt, cores))
-        if it > 0:
+        if it >= warm:
             times.append(dt)
     med = sorted(times)[len(times) // 2]
     return {'value': round(edges / med / 1e6, 4), 'unit': 'M-edges/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 icosphere n=%d (F=%d, %d edges), fwd+loss+bwd, median of %d after 1 warm-up, %.2f s each; '
+            'sample': '1 icosphere n=%d (F=%d, %d edges), fwd+loss+bwd, median of %d after %d warm-ups, %.2f s each; '
                       'torch %s CPU, PyG-shaped per-edge op decomposition (oracle/)' %
-                      (freq, 20 * freq * freq, edges, timed, med, torch.__version__)}
+                      (freq, 20 * freq * freq, edges, timed, warm, med, torch.__version__)}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start the N ranks as a CHILD
+    `python -m torch.distributed.run` process, relay rank 0's JSON line, return the child's exit code.
+
+    Runs before anything in this process touches the GPU (torch.cuda.device_count() does not initialise
+    it on this image) and never exec()s.  When the box shows fewer devices than ranks (the 1-GPU lease),
+    the ranks share device 0 over gloo -- a REHEARSAL of the multi-rank path, labelled as such in the
+    line; it is not a scaling measurement."""
+    import subprocess
+    n = args.gpus
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    have = torch.cuda.device_count()
+    if have < n:
+        if n > 4:
+            log('only %d device(s) visible: a %d-rank rehearsal on one device exceeds the process guard of a 1-GPU box' % (have, n))
+            return 2
+        log('only %d device(s) visible for %d ranks: rehearsal on device 0 over gloo' % (have, n))
+        env['GEOBI_ALL_RANKS_ON_DEVICE0'] = '1'
+        env['GEOBI_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    log('launching: ' + ' '.join(cmd))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:
+        out = out.rstrip('\n')
+        if out.startswith('{') and '"metric"' in out:
+            line = out
+        elif out:
+            log('[child] ' + out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log('the ranks exited cleanly but printed no result line')
+        rc = 1
+    return rc
 
 
 def main():
@@ -202,15 +249,38 @@ def main():
     ap.add_argument('--freq', type=int, default=FREQ, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--plumbing', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch.distributed as dist
     from geobi_gnn_amd import network, _lib
     from geobi_gnn_amd.parallel import init_distributed, FlatParameters
 
     rank, world, device = init_distributed()
+    if args.plumbing:
+        # launcher / rendezvous / collective plumbing only (tests/test_host_logic.py drives the N > 1 branch on a
+        # box without a GPU): no workload runs and no number is reported
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'M-edges/s (fwd+bwd) on Synthetic set', 'value': None, 'n_gpus': world,
+                              'plumbing': True, 'rank_sum': t.item(), 'backend': dist.get_backend() if world > 1 else None}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if world != args.gpus:
+        raise SystemExit('bench.py: WORLD_SIZE=%d but --gpus %d (launch through torch.distributed.run '
+                         '--nproc-per-node %d, or from a bare shell)' % (world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no CPU fallback exists'
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
+    rehearsal = os.environ.get('GEOBI_ALL_RANKS_ON_DEVICE0') == '1' and world > 1
     _lib.lib()
 
     torch.manual_seed(0)                                  # random-init weights of the real architecture
@@ -257,8 +327,13 @@ def main():
                                'disjoint-union graph, L1/L1 loss, grad all-reduce + Adam step inside the timed '
                                'region' % (args.freq, 20 * args.freq ** 2),
                    'meshes_per_rank': BATCH, 'edges_per_rank_step': edges, 'parallelism': 'dp%d' % world,
+                   'collective': ('none' if world == 1 else
+                                  '%s all-reduce of the flat fp32 gradient bucket' % dist.get_backend()),
                    'final_loss': round(float(loss.item()), 6)},
     }
+    if rehearsal:
+        out['config']['rehearsal'] = ('%d ranks share device 0 over gloo (fewer devices than ranks): checks the '
+                                      'multi-rank path, NOT a scaling measurement' % world)
     if rank == 0:
         if not args.no_roofline:
             out['roofline'] = measure_roofline(net, bucket, opt, dv, df)

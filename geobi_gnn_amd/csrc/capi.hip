@@ -171,7 +171,7 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
                     const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
                     const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
-                    float* dbias, void* ws, size_t ws_bytes, void* stream) {
+                    float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(rowptr_out); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c);
   NOTNULL(gout); NOTNULL(p); NOTNULL(z); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
   if (slope != 1.0f) NOTNULL(out);
@@ -179,7 +179,8 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
   if (E > 0) { NOTNULL(col_in); NOTNULL(col_out); NOTNULL(pos_in); }
   GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
   return feast_bwd(xa, Cb > 0 ? xb : nullptr, Ca, Cb, N, E, rowptr_in, col_in, rowptr_out, col_out, pos_in, lin_w,
-                   u_w, c, Cout, slope, out, gout, p, z, wf, dxa, dxb, dlin_w, du_w, dc, dbias, ws, ws_bytes, S(stream));
+                   u_w, c, Cout, slope, out, gout, p, z, wf, dxa, dxb, dlin_w, du_w, dc, dbias, accumulate, ws, ws_bytes,
+                   S(stream));
 }
 
 int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,
@@ -287,12 +288,12 @@ int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const fl
 size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K) { return head_bwd_ws_bytes(N, Cin, K); }
 int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
-                   float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
-                   void* stream) {
+                   float* dx, float* dw1, float* db1, float* dw2, float* db2, int accumulate, void* ws,
+                   size_t ws_bytes, void* stream) {
   NOTNULL(x); NOTNULL(w1); NOTNULL(w2); NOTNULL(raw); NOTNULL(gout);
   NOTNULL(dw1); NOTNULL(db1); NOTNULL(dw2); NOTNULL(db2);
-  return head_bwd(x, Cin, N, w1, b1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, ws, ws_bytes,
-                  S(stream));
+  return head_bwd(x, Cin, N, w1, b1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, accumulate, ws,
+                  ws_bytes, S(stream));
 }
 
 size_t geobi_row_loss_ws_bytes(int64_t n) { return row_loss_ws_bytes(n); }

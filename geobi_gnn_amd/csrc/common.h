@@ -109,6 +109,7 @@ struct TnOutput {
   float* C2 = nullptr;  // secondary output (bias gradient / c gradient)
   int Cin = 0, Cout = 0;
   int extra_row = 0, extra_col = 0;  // TN_PLAIN: last row / column is the implicit-ones one -> C2
+  int accumulate = 0;   // != 0: add to what C / C2 hold (gradient accumulation) instead of overwriting
 };
 // I, J: logical output sizes INCLUDING an implicit ones row / column when ones_row / ones_col >= 0
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
@@ -128,7 +129,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
               const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
               const float* gout, const float* p, const float* z, const float* wf_saved, float* dxa, float* dxb,
-              float* dlin_w, float* du_w, float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+              float* dlin_w, float* du_w, float* dc, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+              hipStream_t s);
 // pool.hip
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
                     float* w_out, hipStream_t s);
@@ -227,9 +229,9 @@ int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
 size_t head_bwd_fused_ws_bytes(int64_t N);
 int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, int nout,
                    float slope, const float* graw, float* dx, float* dw1, float* db1, float* dw2, float* db2,
-                   void* ws, size_t ws_bytes, hipStream_t s);
+                   int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2, int nout,
              float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx, float* dw1,
-             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s);
+             float* db1, float* dw2, float* db2, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace geobi

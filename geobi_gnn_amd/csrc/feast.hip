@@ -612,7 +612,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
               const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,
               const float* gout, const float* p, const float* z, const float* wf_saved, float* dxa, float* dxb,
-              float* dlin_w, float* du_w, float* dc, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+              float* dlin_w, float* du_w, float* dc, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+              hipStream_t s) {
   const int Cin = Ca + Cb;
   const int Kp = feast_ldz(Cin), ldr = feast_ldr(Cout);
   GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_bwd: bad node count");
@@ -634,7 +635,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   Fork fk = fork_side_stream(s);
   {
     TnOutput ow;
-    ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout;
+    ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout; ow.accumulate = accumulate;
     GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, fk.side ? fk.side : s));
   }
   // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
@@ -664,7 +665,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     GEOBI_TRY(side_wait_main(fk, s));
     hipStream_t ss = fk.side ? fk.side : s;
     TnOutput ou;
-    ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc;
+    ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc; ou.accumulate = accumulate;
     GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws2, b.tn_bytes2, ss));
     if (Cb) {
       ou.C = du_w + Ca; ou.C2 = nullptr;

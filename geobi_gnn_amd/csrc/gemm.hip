@@ -463,24 +463,28 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, in
 #pragma unroll 8
   for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * I * J + idx];
   int i = idx / J, j = idx % J;
+  float* dst = nullptr;
   if (o.mode == TN_PLAIN) {
     // an implicit ones row / column (always the last one) lands in C2
-    if (o.extra_row && i == I - 1) { if (!(o.extra_col && j == J - 1)) o.C2[j] = s; }
-    else if (o.extra_col && j == J - 1) o.C2[i] = s;
-    else o.C[(size_t)i * o.ldc + j] = s;
+    if (o.extra_row && i == I - 1) { if (!(o.extra_col && j == J - 1)) dst = o.C2 + j; }
+    else if (o.extra_col && j == J - 1) dst = o.C2 + i;
+    else dst = o.C + (size_t)i * o.ldc + j;
   } else if (o.mode == TN_LIN_UNPACK) {
     // rows are (head h, in-channel k) of the packed weight, columns are out-channels:
     // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`); the implicit ones row
     // (i == I - 1) carries the bias gradient
-    if (i == I - 1) { o.C2[j] = s; return; }
-    int h = i / o.Cin, k = i % o.Cin;
-    if (h < GEOBI_H) o.C[((size_t)h * o.Cout + j) * o.Cin + k] = s;
+    if (i == I - 1) dst = o.C2 + j;
+    else {
+      int h = i / o.Cin, k = i % o.Cin;
+      if (h < GEOBI_H) dst = o.C + ((size_t)h * o.Cout + j) * o.Cin + k;
+    }
   } else {
     // TN_DU_DC: A = [dp (rows 0..8) | pad | dcs (rows 12..20) | pad], B = [x | 1]
     //   du[h, col0 + j] = row h, j < J-1 ;   dc[h] = row 12+h, j == J-1
-    if (j < J - 1) { if (i < GEOBI_H) o.C[(size_t)i * o.ldc + j] = s; }
-    else if (o.C2 != nullptr && i >= GEOBI_HP && i < GEOBI_HP + GEOBI_H) o.C2[i - GEOBI_HP] = s;
+    if (j < J - 1) { if (i < GEOBI_H) dst = o.C + (size_t)i * o.ldc + j; }
+    else if (o.C2 != nullptr && i >= GEOBI_HP && i < GEOBI_HP + GEOBI_H) dst = o.C2 + (i - GEOBI_HP);
   }
+  if (dst != nullptr) *dst = o.accumulate ? *dst + s : s;
 }
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, int lda, int64_t M, int J,

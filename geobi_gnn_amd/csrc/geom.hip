@@ -374,7 +374,7 @@ size_t head_bwd_ws_bytes(int64_t N, int Cin, int K) {
 
 int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2, int nout,
              float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout, float* dx,
-             float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, hipStream_t s) {
+             float* dw1, float* db1, float* dw2, float* db2, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   Arena a(ws, ws_bytes);
   float* graw = a.take<float>((size_t)N * 3);
   if (h == nullptr) {   // fused path (forward did not save the hidden activation): recompute it in-kernel
@@ -385,7 +385,7 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
     GEOBI_REQUIRE(a.ok() && ws, "head_bwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
     head_finish_bwd_kernel<<<cdiv(N, 256), 256, 0, s>>>(gout, raw, nout, mode, dd, (int)N, graw);
     GEOBI_LAUNCH_OK();
-    return head_bwd_fused(x, N, w1, b1, w2, nout, slope, graw, dx, dw1, db1, dw2, db2, fws, fb, s);
+    return head_bwd_fused(x, N, w1, b1, w2, nout, slope, graw, dx, dw1, db1, dw2, db2, accumulate, fws, fb, s);
   }
   float* dh = a.take<float>((size_t)N * K);
   size_t t1 = gemm_tn_ws_bytes(K, Cin + 1, N), t2 = gemm_tn_ws_bytes(3, K + 1, N);
@@ -396,13 +396,13 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
   GEOBI_LAUNCH_OK();
   // dW2 = graw^T h and db2 = graw^T 1 in one pass (implicit ones column appended to h)
   TnOutput o2;
-  o2.C = dw2; o2.ldc = K; o2.C2 = db2; o2.extra_col = 1;
+  o2.C = dw2; o2.ldc = K; o2.C2 = db2; o2.extra_col = 1; o2.accumulate = accumulate;
   GEOBI_TRY(gemm_tn(graw, nout, h, K, N, nout, K + 1, -1, K, o2, tn_ws, tnb, s));
   head_dh_kernel<<<cdiv(N * K / 4, 256), 256, 0, s>>>(graw, nout, w2, h, K, slope, N * K, dh);
   GEOBI_LAUNCH_OK();
   // dW1 = dh^T x and db1 = dh^T 1
   TnOutput o1;
-  o1.C = dw1; o1.ldc = Cin; o1.C2 = db1; o1.extra_col = 1;
+  o1.C = dw1; o1.ldc = Cin; o1.C2 = db1; o1.extra_col = 1; o1.accumulate = accumulate;
   GEOBI_TRY(gemm_tn(dh, K, x, Cin, N, K, Cin + 1, -1, Cin, o1, tn_ws, tnb, s));
   if (dx) {
     GemmEpilogue ep;

@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
 
 __global__ void head_bwd_reduce_kernel(const float* __restrict__ p_dw1, const float* __restrict__ p_dw2,
                                        const float* __restrict__ p_db1, const float* __restrict__ p_db2,
-                                       int blocks, int nout, float* __restrict__ dw1, float* __restrict__ db1,
-                                       float* __restrict__ dw2, float* __restrict__ db2) {
+                                       int blocks, int nout, int accumulate, float* __restrict__ dw1,
+                                       float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_dw1 = HID * CIN;
   if (idx < n_dw1) {
@@ -285,24 +285,24 @@ __global__ void head_bwd_reduce_kernel(const float* __restrict__ p_dw1, const fl
     float s = 0.f;
 #pragma unroll 8
     for (int b = 0; b < blocks; ++b) s += p_dw1[(size_t)b * (NCHUNK * 16 * 64) + off];
-    dw1[idx] = s;
+    dw1[idx] = accumulate ? dw1[idx] + s : s;
   } else if (idx < n_dw1 + HID) {
     const int j = idx - n_dw1;
     float s = 0.f;
 #pragma unroll 8
     for (int b = 0; b < blocks; ++b) s += p_db1[(size_t)b * HID + j];
-    db1[j] = s;
+    db1[j] = accumulate ? db1[j] + s : s;
   } else if (idx < n_dw1 + HID + nout * HID) {
     const int e = idx - n_dw1 - HID;
     float s = 0.f;
 #pragma unroll 8
     for (int b = 0; b < blocks; ++b) s += p_dw2[(size_t)b * nout * HID + e];
-    dw2[e] = s;
+    dw2[e] = accumulate ? dw2[e] + s : s;
   } else if (idx < n_dw1 + HID + nout * HID + nout) {
     const int o = idx - n_dw1 - HID - nout * HID;
     float s = 0.f;
     for (int b = 0; b < blocks; ++b) s += p_db2[(size_t)b * 4 + o];
-    db2[o] = s;
+    db2[o] = accumulate ? db2[o] + s : s;
   }
 }
 
@@ -338,7 +338,7 @@ size_t head_bwd_fused_ws_bytes(int64_t N) {
 // graw [N, nout] is the gradient w.r.t. the pre-finish head output (head_finish_bwd in geom.hip).
 int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, int nout,
                    float slope, const float* graw, float* dx, float* dw1, float* db1, float* dw2, float* db2,
-                   void* ws, size_t ws_bytes, hipStream_t s) {
+                   int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   const int blocks = bwd_blocks(N);
   Arena a(ws, ws_bytes);
   float* p_dw1 = a.take<float>((size_t)blocks * NCHUNK * 16 * 64);
@@ -365,8 +365,8 @@ int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
                                                        p_db1, p_db2);
   GEOBI_LAUNCH_OK();
   const int total = HID * CIN + HID + nout * HID + nout;
-  head_bwd_reduce_kernel<<<cdiv(total, 256), 256, 0, s>>>(p_dw1, p_dw2, p_db1, p_db2, blocks, nout, dw1, db1, dw2,
-                                                          db2);
+  head_bwd_reduce_kernel<<<cdiv(total, 256), 256, 0, s>>>(p_dw1, p_dw2, p_db1, p_db2, blocks, nout, accumulate, dw1, db1,
+                                                          dw2, db2);
   GEOBI_LAUNCH_OK();
   return 0;
 }

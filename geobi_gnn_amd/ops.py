@@ -130,12 +130,17 @@ def _direct_grad(p):
     """Gradient buffer the kernels may write into directly.
 
     parallel.GradBucket(direct=True) marks parameters whose ``.grad`` is a persistent view of the
-    flat bucket (zeroed every step, each parameter used once per step).  The backward kernels then
-    store the gradient straight into that view and autograd receives ``None`` -- this removes one
-    accumulate kernel per parameter (76 per step)."""
-    if getattr(p, '_geobi_direct_grad', False) and p.grad is not None and p.grad.is_contiguous():
-        return p.grad
-    return None
+    flat bucket.  The backward kernels then ADD the gradient straight into that view (`accumulate`
+    argument of geobi_feast_bwd / geobi_head_bwd) and autograd receives ``None`` -- this removes one
+    accumulate kernel per parameter (76 per step) and keeps autograd's semantics: several backward
+    passes between two ``bucket.zero()`` calls sum up (the reference's gradient accumulation,
+    train_dual.py:211-218), and so do several uses of one parameter in a forward."""
+    if not getattr(p, '_geobi_direct_grad', False):
+        return None
+    if p.grad is None or not p.grad.is_contiguous() or getattr(p, '_geobi_grad_ptr', None) != p.grad.data_ptr():
+        raise L.GeobiError('a direct-gradient parameter lost its bucket view (optimizer.zero_grad(set_to_none=True) or '
+                           'an assignment to .grad): zero the gradients with GradBucket.zero() instead')
+    return p.grad
 
 
 def _f32c(t):
@@ -210,7 +215,7 @@ class FeastConvFn(Function):
         L.call('geobi_feast_bwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(g.rowptr_out), L.ptr(g.col_out), L.ptr(g.pos_in), L.ptr(lin_w), L.ptr(u_w), L.ptr(c), Cout,
                ctx.slope, L.ptr(out), L.ptr(gout), L.ptr(p), L.ptr(z), L.ptr(wf), L.ptr(dxa), L.ptr(dxb), L.ptr(dlin),
-               L.ptr(du), L.ptr(dc), L.ptr(dbias), L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(du), L.ptr(dc), L.ptr(dbias), 1 if ret[0] is None else 0, L.ptr(ws), ws.numel(), L.stream())
         if _SIDE_KEEP[0] is not None:
             _SIDE_KEEP[0].append((ws, gout, dlin, du, dc, dbias))
         return (dxa, dxb) + ret + (None, None)
@@ -421,7 +426,7 @@ class HeadFn(Function):
         ws = L.workspace(L.size_query('geobi_head_bwd_ws_bytes', N, Cin, K), dev)
         L.call('geobi_head_bwd', L.ptr(x), Cin, N, L.ptr(w1), L.ptr(b1), K, L.ptr(w2), nout, LEAK, ctx.mode,
                L.ptr(dd), L.ptr(h), L.ptr(raw), L.ptr(gout), L.ptr(dx), L.ptr(dw1), L.ptr(db1), L.ptr(dw2),
-               L.ptr(db2), L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(db2), 1 if ret[0] is None else 0, L.ptr(ws), ws.numel(), L.stream())
         return (dx,) + ret + (None, None, None)
 
 

@@ -50,25 +50,35 @@ class GradBucket(object):
     data-parallel reduction is one all-reduce, and nothing is copied in or out."""
 
     def __init__(self, params, direct=False):
-        """direct=True lets the backward kernels store gradients straight into the bucket views
-        (ops._direct_grad); valid while every parameter is used once per step and `zero()` is
-        called before each backward -- the way bench.py and the training loop drive it."""
+        """direct=True lets the backward kernels ADD gradients straight into the bucket views
+        (ops._direct_grad, `accumulate` in the C ABI): same semantics as autograd's accumulation into
+        ``.grad`` -- backward passes between two `zero()` calls sum up -- without the per-parameter
+        accumulate kernels."""
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.owner = None            # FlatParameters: the flat Parameter whose .grad must stay `self.flat`
+        self._views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            v = self.flat[off:off + n].view_as(p)
+            self._views.append(v)
+            p.grad = v
             p._geobi_direct_grad = bool(direct)
+            p._geobi_grad_ptr = v.data_ptr()
             off += n
 
     def zero(self):
+        """Zero every gradient (one memset) and re-attach any view an optimizer's
+        ``zero_grad(set_to_none=True)`` or a stray assignment dropped since the last call."""
         self.flat.zero_()
-        for p in self.params:        # an optimizer's zero_grad(set_to_none=True) would detach the views
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr():
-                raise RuntimeError('GradBucket: a gradient view was replaced; use bucket.zero(), not zero_grad()')
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+        if self.owner is not None and self.owner.grad is not self.flat:
+            self.owner.grad = self.flat
 
     def all_reduce_mean(self):
         """Sum over ranks then divide by the world size (= the reference's loss / batch_size)."""
@@ -95,6 +105,7 @@ class FlatParameters(object):
             p.data = self.flat_param.data[off:off + n].view_as(p)
             off += n
         self.bucket = GradBucket(params, direct=direct)
+        self.bucket.owner = self.flat_param
         self.flat_param.grad = self.bucket.flat
 
     def parameters(self):

@@ -88,13 +88,15 @@ int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
                     float* wf, void* ws, size_t ws_bytes, void* stream);
 size_t geobi_feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
-/* dxa/dxb may be NULL (input needs no gradient); dlin_w/du_w/dc/dbias are overwritten. */
+/* dxa/dxb may be NULL (input needs no gradient); dlin_w/du_w/dc/dbias are overwritten, or added to when
+ * accumulate != 0 (a caller that lets the kernels write into persistent .grad storage: gradient accumulation
+ * over several backward passes, code/train_dual.py:211-218). */
 int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E,
                     const int32_t* rowptr_in, const int32_t* col_in, const int32_t* rowptr_out,
                     const int32_t* col_out, const int32_t* pos_in, const float* lin_w, const float* u_w,
                     const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
                     const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
-                    float* dbias, void* ws, size_t ws_bytes, void* stream);
+                    float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- pooling ------------------
  * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10
@@ -196,8 +198,8 @@ int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const fl
 size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K);
 int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
-                   float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
-                   void* stream);
+                   float* dx, float* dw1, float* db1, float* dw2, float* db2, int accumulate, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- losses / metrics ---------
  * code/network.py:364-413 on [n, 3] rows:  out[0] = scale * sum_i w_i * term_i  (w = NULL: w_i = 1)

@@ -320,6 +320,51 @@ def test_direct_gradient_writes_match_autograd_accumulation(dev):
     assert torch.equal(grads(), g_ref)                        # and stays valid step after step
 
 
+def test_direct_gradients_accumulate_like_autograd(dev):
+    """two backward() calls between bucket.zero() calls must SUM in the bucket (the reference's gradient
+    accumulation over batch_size single-mesh steps, train_dual.py:211-218); an optimizer's zero_grad(set_to_none)
+    must not silently disconnect the bucket."""
+    from geobi_gnn_amd import network, meshgen
+    from geobi_gnn_amd._lib import GeobiError
+    from geobi_gnn_amd.parallel import FlatParameters
+    torch.manual_seed(4)
+    net = network.DualGNN().to(dev)
+    meshes = [[t.to(dev) for t in meshgen.synthetic_dual_data(6, 0.2, seed=9 + i)] for i in range(2)]
+
+    def backward(i):
+        dv, df = meshes[i][0].shallow_copy(), meshes[i][1].shallow_copy()
+        vp, npred, _ = net((dv, df))
+        network.dual_loss(network.loss_v(vp, meshes[i][0].y, 'L1'), network.loss_n(npred, meshes[i][1].y, 'L1')).backward()
+
+    def flat_grads():
+        return torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+
+    net.zero_grad()
+    backward(0)
+    g0 = flat_grads()
+    net.zero_grad()
+    backward(1)
+    g1 = flat_grads()
+    flat = FlatParameters(net, direct=True)
+    opt = torch.optim.SGD(flat.parameters(), lr=0.0)
+    flat.bucket.zero()
+    backward(0)
+    backward(1)
+    assert torch.equal(flat.bucket.flat, g0 + g1)               # accumulated, not overwritten
+    assert flat.flat_param.grad is flat.bucket.flat
+    # the optimizer's own zero_grad drops .grad (set_to_none): the next backward must refuse, not lose gradients
+    opt.zero_grad()
+    assert flat.flat_param.grad is None
+    for p in net.parameters():
+        p.grad = None
+    with pytest.raises(GeobiError, match='GradBucket.zero'):
+        backward(0)
+    flat.bucket.zero()                                            # re-attaches every view and the flat .grad
+    assert flat.flat_param.grad is flat.bucket.flat
+    backward(0)
+    assert torch.equal(flat.bucket.flat, g0)
+
+
 def test_losses_and_metrics_match_reference_fixture(dev):
     """network.loss_v / loss_n / error_v / error_n (fused reduction kernels) vs the values the reference's
     own functions produced (tests/golden/pure_functions.npz) and vs autograd of the oracle."""

@@ -312,3 +312,34 @@ def test_random_rotate_is_a_rigid_motion_of_both_graphs():
         assert torch.allclose(dv.x[:, :3].norm(dim=1), ref[0].x[:, :3].norm(dim=1), atol=1e-4)
         if z_only:
             assert torch.allclose(dv.x[:, 2], ref[0].x[:, 2], atol=1e-6)
+
+
+def _run_bench(*argv, **env_extra):
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, text=True,
+                          capture_output=True, timeout=240)
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent starts torch.distributed.run as a child, the two
+    ranks rendezvous over gloo, rank 0's single JSON line comes back through the parent."""
+    import json
+    r = _run_bench('--gpus', '2', '--plumbing')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rank_sum'] == 3.0 and out['backend'] == 'gloo'
+    assert 'torch.distributed.run' in r.stderr and '--nproc-per-node 2' in r.stderr
+
+
+def test_bench_relays_a_failing_child_and_checks_world_size():
+    # no GPU here: the ranks refuse to run the workload; the parent must exit non-zero and print no result line
+    r = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0')
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    # launched by an outer torchrun with a different world size: refused, not silently mis-reported
+    r = _run_bench('--gpus', '2', '--steps', '1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    assert r.returncode != 0 and 'WORLD_SIZE=1 but --gpus 2' in r.stderr
