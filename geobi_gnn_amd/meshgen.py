@@ -157,16 +157,16 @@ def facet_graph_index(faces, vf):
     return np.stack([row, col], 0)
 
 
-def calc_weight(node_pos, node_normal, edge_index):
-    """data_util.py:383-398, torch fp32 like the reference."""
-    eps = 0.001
-    edge_len = node_pos[edge_index]
-    edge_len = ((edge_len[0] - edge_len[1]) ** 2).sum(1)
-    edge_len_mean = (edge_len ** 0.5).mean()
-    normal_pair = node_normal[edge_index]
-    dn = (normal_pair[0] * normal_pair[1]).sum(1)
-    dp = (edge_len / (-2 * edge_len_mean + 1e-12)).exp()
-    return torch.clamp(dn, eps) * dp
+def bilateral_edge_weight(pos, normal, edge_index):
+    """The static edge weight the dataset stores (what data_util.py:383-398 defines):
+    max(n_s . n_t, 1e-3) * exp(-|p_s - p_t|^2 / (2 * mean edge length)), the mean running over every
+    listed edge, loops included.  Host-side generator only; the device path is meshprep.calc_weight
+    (csrc/meshprep.hip: calc_weight_kernel), pinned by tests/golden/pure_functions.npz."""
+    src, dst = edge_index[0], edge_index[1]
+    sq_len = (pos[src] - pos[dst]).pow(2).sum(1)
+    two_sigma = 2 * sq_len.sqrt().mean() - 1e-12
+    cos_angle = (normal[src] * normal[dst]).sum(1).clamp_min(1e-3)
+    return cos_angle * torch.exp(-sq_len / two_sigma)
 
 
 def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type='Synthetic'):
@@ -187,12 +187,12 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
     pos_v = torch.from_numpy(pn).float()
     normal_v = torch.from_numpy(vn).float()
     ei_v = torch.from_numpy(vertex_graph_index(faces, V)).long()
-    ew_v = calc_weight(pos_v, normal_v, ei_v).float()
+    ew_v = bilateral_edge_weight(pos_v, normal_v, ei_v).float()
 
     pos_f = pos_v[fv_t].mean(1).float()
     normal_f = torch.from_numpy(fn).float()
     ei_f = torch.from_numpy(facet_graph_index(faces, vf)).long()
-    ew_f = calc_weight(pos_f, normal_f, ei_f).float()
+    ew_f = bilateral_edge_weight(pos_f, normal_f, ei_f).float()
 
     cen = torch.from_numpy(centroid).float()
     sc = float(scale)

@@ -150,7 +150,16 @@ def gen_pure_functions():
     clus = torch.from_numpy(rng.integers(0, 40, size=noisy.shape[0]))
     pe_i, pe_w = ref_net_util.pool_edge(clus, ei, cw)
     pf = ref_net_util.pool_face(clus, fv)
+    # graph assembly (dataset.py:197-233): the reference's own build_facet_graph / center_and_scale on the host
+    # generator's incidence tables (coalesce is the shimmed one); the vertex graph is to_undirected + add_self_loops
+    # of the edge list, i.e. shim calls only, so it is restated rather than pinned
+    facet_ei = ref_data_util.build_facet_graph(fv.long(), vf.long())
+    assert np.array_equal(facet_ei.numpy(), meshgen.facet_graph_index(faces, vf.numpy())), 'facet graph differs'
+    ev = torch.from_numpy(meshgen.mesh_edges(faces)).long()
+    pts_cs, cen_cs, scale_cs = ref_data_util.center_and_scale(pts, ev, 0)
     fx = dict(points=noisy, faces=faces.astype(np.int32), vf=vf.numpy().astype(np.int32),
+              facet_graph_index=facet_ei.numpy().astype(np.int32), mesh_edges=ev.numpy().astype(np.int32),
+              centered_scaled=pts_cs.numpy(), centroid=cen_cs.numpy(), scale=np.float32(scale_cs),
               face_normal=fnrm.numpy(), edge_index=ei.numpy().astype(np.int32), vnormal=vn.numpy(),
               calc_weight=cw.numpy(), gt_normal=gt_n.numpy(), update2=up.numpy(), update2_depth=up_d.numpy(),
               depth_direction=dd.numpy(), a=a.numpy(), b=b.numpy(),

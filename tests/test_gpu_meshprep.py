@@ -108,6 +108,12 @@ def test_pinned_by_reference_calc_weight(dev):
     np.testing.assert_allclose(got.cpu().numpy(), w, rtol=3e-6, atol=1e-7)
     loops = fx['calc_weight'][fx['edge_index'][0] == fx['edge_index'][1]]
     np.testing.assert_allclose(loops, 1.0, rtol=1e-6)          # what reference_layout=True appends
+    # facet graph of the reference's own build_facet_graph (self loops inline) and its centre / scale
+    dv, df = meshprep.build_dual_data(fx['points'], fx['faces'].astype(np.int64), device=dev, reference_layout=True)
+    assert np.array_equal(df.edge_index.cpu().numpy(), fx['facet_graph_index'].astype(np.int64))
+    np.testing.assert_allclose(dv.x[:, :3].cpu().numpy(), fx['centered_scaled'], rtol=0,
+                               atol=2e-6 * np.abs(fx['centered_scaled']).max())
+    assert abs(dv.meta['scale'] - float(fx['scale'])) <= 2e-6 * float(fx['scale'])
 
 
 def test_network_on_device_built_inputs(dev):

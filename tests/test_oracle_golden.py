@@ -57,7 +57,7 @@ def test_pure_functions():
     pts, fv, vf = t('points'), t('faces').long(), t('vf').long()
     assert torch.equal(R.computer_face_normal(pts, fv), t('face_normal'))
     from geobi_gnn_amd import meshgen
-    assert torch.equal(meshgen.calc_weight(pts, t('vnormal'), t('edge_index').long()), t('calc_weight'))
+    assert torch.equal(meshgen.bilateral_edge_weight(pts, t('vnormal'), t('edge_index').long()), t('calc_weight'))
     assert torch.equal(R.update_position2(pts, fv, vf, t('gt_normal'), n_iter=5), t('update2'))
     assert torch.equal(R.update_position2(pts, fv, vf, t('gt_normal'), n_iter=3, depth_direction=t('depth_direction')),
                        t('update2_depth'))
@@ -74,6 +74,21 @@ def test_pure_functions():
     pe_i, pe_w = R.pool_edge(t('cluster').long(), t('edge_index').long(), t('calc_weight'))
     assert torch.equal(pe_i, t('pool_edge_index').long()) and torch.equal(pe_w, t('pool_edge_weight'))
     assert torch.equal(R.pool_face(t('cluster').long(), fv), t('pool_face').long())
+
+
+def test_host_generator_graphs_match_reference_builders():
+    """meshgen (the host generator that feeds the bench and the parity tests) against the outputs of the reference's
+    own data_util.build_facet_graph and data_util.center_and_scale on this mesh (pure_functions.npz)."""
+    from geobi_gnn_amd import meshgen
+    fx = load_fixture('pure_functions.npz')
+    faces, vf, pts = fx['faces'].astype(np.int64), fx['vf'].astype(np.int64), fx['points']
+    assert np.array_equal(meshgen.vertex_faces(faces, pts.shape[0]), vf)
+    assert np.array_equal(meshgen.facet_graph_index(faces, vf), fx['facet_graph_index'].astype(np.int64))
+    assert np.array_equal(meshgen.mesh_edges(faces), fx['mesh_edges'].astype(np.int64))
+    dv, df = meshgen.build_dual_data(pts, faces)
+    assert torch.equal(df.edge_index, torch.from_numpy(fx['facet_graph_index']).long())
+    np.testing.assert_allclose(dv.x[:, :3].numpy(), fx['centered_scaled'], rtol=0, atol=2e-6 * np.abs(fx['centered_scaled']).max())
+    assert abs(dv.meta['scale'] - float(fx['scale'])) <= 1e-6 * float(fx['scale'])
 
 
 def test_graclus_c_matches_python_loop():
@@ -113,3 +128,4 @@ def test_feast_properties():
     out_a = conv(x, ei)
     out_b = conv(x[perm], inv[ei])
     assert torch.allclose(out_a[perm], out_b, atol=1e-10)
+
