@@ -80,6 +80,53 @@ __device__ __forceinline__ void store_vec(float* __restrict__ ptr, const float (
   }
 }
 
+// Per-edge logits of the layers that read raw mesh coordinates (Cin = 6 / 12, level 0): there the features are
+// positions scaled by 1 / mean edge length, |x| ~ 27 at n = 32 and ~ 72 at n = 87, and the node-level form
+// p_j - p_i (p = x u^T) loses |x| / |x_j - x_i| in the subtraction.  These layers therefore evaluate
+// u (x_j - x_i) per edge exactly as the reference does: the difference of two nearby coordinates is (nearly)
+// exact in fp32, and a level-0 row is only 24 / 48 B -- no more than the 48-B logit row it replaces.
+// LDS image of u: [LC][HP] (head-minor, 3 x float4 per input channel).
+template <int LC>
+__device__ __forceinline__ void stage_u(const float* __restrict__ u, float* s_u) {
+  for (int i = threadIdx.x; i < LC * HP; i += blockDim.x) {
+    const int k = i / HP, h = i % HP;
+    s_u[i] = h < H ? u[h * LC + k] : 0.f;
+  }
+  __syncthreads();
+}
+
+template <int LC>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, float (&v)[LC]) {
+  if constexpr ((LC & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < LC; i += 4) {
+      float4 t = *reinterpret_cast<const float4*>(row + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < LC; i += 2) {
+      float2 t = *reinterpret_cast<const float2*>(row + i);
+      v[i] = t.x; v[i + 1] = t.y;
+    }
+  }
+}
+
+// l_h = c_h + sum_k u[h,k] d[k]
+template <int LC>
+__device__ __forceinline__ void edge_logits(const float (&d)[LC], const float* s_u, const float (&cc)[H], float (&l)[H]) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) l[h] = cc[h];
+#pragma unroll
+  for (int k = 0; k < LC; ++k) {
+    const float4* r = reinterpret_cast<const float4*>(s_u + k * HP);
+    const float4 a = r[0], b = r[1], c = r[2];
+    l[0] = fmaf(a.x, d[k], l[0]); l[1] = fmaf(a.y, d[k], l[1]); l[2] = fmaf(a.z, d[k], l[2]);
+    l[3] = fmaf(a.w, d[k], l[3]); l[4] = fmaf(b.x, d[k], l[4]); l[5] = fmaf(b.y, d[k], l[5]);
+    l[6] = fmaf(b.z, d[k], l[6]); l[7] = fmaf(b.w, d[k], l[7]); l[8] = fmaf(c.x, d[k], l[8]);
+  }
+}
+
 // ----------------------------------------------------------------------------- logits
 template <int C>
 __global__ __launch_bounds__(256) void feast_logits_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
@@ -128,15 +175,19 @@ __global__ __launch_bounds__(256) void feast_logits_kernel(const float* __restri
 // MODE 0: forward  z_i[h,:] = 1/deg_i (q_self x_i + sum_j q_ij x_j),  logits p_j - p_i + c
 // MODE 1: backward transposed   r_j[h,:] = sum_i q_ij / deg_i g_i  (+ self), logits p_ctr - p_nbr + c,
 //         walking the CSR of the OTHER direction; deg comes from `deg_rowptr`.
-template <int C, int VEC, int MODE>
+// LC > 0: logits from the raw rows `xl` [N, LC] and `ul` [H, LC] per edge (see edge_logits) instead of `p`.
+template <int C, int VEC, int MODE, int LC>
 __global__ __launch_bounds__(256) void feast_aggregate_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const int* __restrict__ deg_rowptr, int N, float* __restrict__ out, int ldo) {
+    const int* __restrict__ deg_rowptr, int N, float* __restrict__ out, int ldo, const float* __restrict__ xl,
+    const float* __restrict__ ul) {
   constexpr int G = C / VEC;
   constexpr int NPW = 64 / G;
   static_assert(G * VEC == C && G >= 2 && (64 % G) == 0, "group shape");
   __shared__ __attribute__((aligned(16))) float s_slot[4][64][HP];
+  __shared__ __attribute__((aligned(16))) float s_u[LC > 0 ? LC * HP : 4];
+  if constexpr (LC > 0) stage_u<LC>(ul, s_u);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / G, k = lane % G;
@@ -155,7 +206,9 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
   if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
 
   float pc[H], cc[H], qs[H];
-  load_hp(p + (size_t)ns * HP, pc);
+  float xc[LC > 0 ? LC : 1];
+  if constexpr (LC > 0) load_row<LC>(xl + (size_t)ns * LC, xc);
+  else load_hp(p + (size_t)ns * HP, pc);
 #pragma unroll
   for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
   softmax9(qs);   // the self edge: u(x_i - x_i) + c = c exactly
@@ -180,10 +233,18 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
       int j = ns;
       if (e < re) {
         j = col[e];
-        float pn[H];
-        load_hp(p + (size_t)j * HP, pn);
+        if constexpr (LC > 0) {
+          float d[LC];
+          load_row<LC>(xl + (size_t)j * LC, d);
 #pragma unroll
-        for (int h = 0; h < H; ++h) q[h] = (MODE == 0) ? (pn[h] - pc[h] + cc[h]) : (pc[h] - pn[h] + cc[h]);
+          for (int i = 0; i < LC; ++i) d[i] = (MODE == 0) ? (d[i] - xc[i]) : (xc[i] - d[i]);
+          edge_logits<LC>(d, s_u, cc, q);
+        } else {
+          float pn[H];
+          load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] = (MODE == 0) ? (pn[h] - pc[h] + cc[h]) : (pc[h] - pn[h] + cc[h]);
+        }
         softmax9(q);
         if constexpr (MODE == 1) {
           float w = 1.0f / (float)(deg_rowptr[j + 1] - deg_rowptr[j] + 1);
@@ -271,15 +332,18 @@ __device__ __forceinline__ float group_allreduce(float v) {
 // For every target i (group of G lanes holding dz_i): per in-edge recompute q, form
 // s_h = dz_i[h,:].x_j, softmax backward dl_h = q_h (s_h - sum q s) / deg_i, write dl per edge
 // and the per-node sums:  dpn_i = sum_j dl_ij  (what flows to -p_i),  dcs_i = dpn_i + dl_self.
-template <int C, int VEC>
+template <int C, int VEC, int LC>
 __global__ __launch_bounds__(256) void feast_rowpass_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ dz, int ldz, int N, float* __restrict__ dl, float* __restrict__ dpn,
-    float* __restrict__ dcs, int ld_dcs) {
+    float* __restrict__ dcs, int ld_dcs, const float* __restrict__ ul) {
   constexpr int G = C / VEC;
   constexpr int NPW = 64 / G;
+  static_assert(LC == 0 || LC == C, "per-edge logits read the layer's own (unsplit) input rows");
   __shared__ __attribute__((aligned(16))) float s_slot[4][64][HP];
+  __shared__ __attribute__((aligned(16))) float s_u[LC > 0 ? LC * HP : 4];
+  if constexpr (LC > 0) stage_u<LC>(ul, s_u);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / G, k = lane % G;
@@ -298,7 +362,9 @@ __global__ __launch_bounds__(256) void feast_rowpass_kernel(
   if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
 
   float pc[H], cc[H], qs[H];
-  load_hp(p + (size_t)ns * HP, pc);
+  float xc[LC > 0 ? LC : 1];
+  if constexpr (LC > 0) load_row<LC>(xa + (size_t)ns * LC, xc);
+  else load_hp(p + (size_t)ns * HP, pc);
 #pragma unroll
   for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
   softmax9(qs);
@@ -337,10 +403,18 @@ __global__ __launch_bounds__(256) void feast_rowpass_kernel(
       int j = ns;
       if (e < re) {
         j = col[e];
-        float pn[H];
-        load_hp(p + (size_t)j * HP, pn);
+        if constexpr (LC > 0) {
+          float d[LC];
+          load_row<LC>(xa + (size_t)j * LC, d);
 #pragma unroll
-        for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+          for (int i = 0; i < LC; ++i) d[i] -= xc[i];
+          edge_logits<LC>(d, s_u, cc, q);
+        } else {
+          float pn[H];
+          load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+        }
         softmax9(q);
       } else {
 #pragma unroll
@@ -414,6 +488,75 @@ __global__ void feast_dp_gather_kernel(const int* __restrict__ rowptr_out, const
   reinterpret_cast<float4*>(rp + (size_t)n * ldr + col0)[q] = s;
 }
 
+// Level-0 layers (per-edge logits): the attention-weight gradient is formed per edge as well,
+//   du[h,k] = sum over in-edges (j -> i) of dl_e,h (x_j[k] - x_i[k]),      dc[h] = sum_i dcs_i,h,
+// the reference's own summation (autograd of u(x_j - x_i)); the node-level form du = dp^T x multiplies by
+// coordinates of magnitude ~n and cancels afterwards.  One thread per target node, fixed-order block and
+// grid reductions (deterministic).
+template <int LC>
+__global__ __launch_bounds__(256) void feast_du_edge_kernel(const float* __restrict__ x, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ col, const float* __restrict__ dl,
+                                                            const float* __restrict__ dcs, int ld_dcs, int N,
+                                                            float* __restrict__ partial) {
+  constexpr int NV = H * LC + H;
+  __shared__ float red[4][NV];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float acc[H][LC], dca[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dca[h] = 0.f;
+#pragma unroll
+    for (int k = 0; k < LC; ++k) acc[h][k] = 0.f;
+  }
+  if (i < N) {
+    float xc[LC];
+    load_row<LC>(x + (size_t)i * LC, xc);
+    load_hp(dcs + (size_t)i * ld_dcs, dca);
+    const int rs = rowptr[i], re = rowptr[i + 1];
+    for (int e = rs; e < re; ++e) {
+      float d[LC], g[H];
+      load_row<LC>(x + (size_t)col[e] * LC, d);
+      load_hp(dl + (size_t)e * HP, g);
+#pragma unroll
+      for (int k = 0; k < LC; ++k) d[k] -= xc[k];
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int k = 0; k < LC; ++k) acc[h][k] = fmaf(g[h], d[k], acc[h][k]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+#pragma unroll
+    for (int k = 0; k < LC; ++k) {
+      float v = acc[h][k];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave][h * LC + k] = v;
+    }
+    float v = dca[h];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][H * LC + h] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV)
+    partial[(size_t)blockIdx.x * NV + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void feast_du_final_kernel(const float* __restrict__ partial, int blocks, int LCn, int accumulate,
+                                      float* __restrict__ du, float* __restrict__ dc) {
+  const int NV = H * LCn + H;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NV) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * NV + t];
+  float* dst = t < H * LCn ? du + t : dc + (t - H * LCn);
+  *dst = accumulate ? *dst + s : s;
+}
+
 // ------------------------------------------------------------------------- small helpers
 __global__ void pack_wf_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int Kp, float* __restrict__ wf) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,24 +604,36 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ gout, const float* __
   g[i] = out[i] > 0.f ? gout[i] : gout[i] * slope;
 }
 
+// per-edge logits apply when the logit-source rows are an unsplit 6- or 12-channel input
+__host__ inline int edge_logit_channels(int Cin, int Cb) { return (Cb == 0 && (Cin == 6 || Cin == 12)) ? Cin : 0; }
+
 template <int MODE>
 int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
                      const int* rowptr, const int* col, const int* deg_rowptr, int N, float* out, int ldo,
-                     hipStream_t s) {
-#define GEOBI_AGG(C_, V_)                                                                                         \
+                     int LC, const float* xl, const float* ul, hipStream_t s) {
+#define GEOBI_AGG(C_, V_, L_)                                                                                    \
   do {                                                                                                            \
     constexpr int NPW_ = 64 / (C_ / V_);                                                                          \
-    feast_aggregate_kernel<C_, V_, MODE><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col,     \
-                                                                            deg_rowptr, N, out, ldo);             \
+    feast_aggregate_kernel<C_, V_, MODE, L_><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(                           \
+        xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, out, ldo, xl, ul);                                       \
   } while (0)
+#define GEOBI_AGG_L(C_, V_)                                                                                       \
+  do {                                                                                                            \
+    if (LC == 0) GEOBI_AGG(C_, V_, 0);                                                                            \
+    else if (LC == 6) GEOBI_AGG(C_, V_, 6);                                                                       \
+    else GEOBI_AGG(C_, V_, 12);                                                                                   \
+  } while (0)
+  if (LC != 0 && LC != 6 && LC != 12) return set_error("feast: per-edge logits take 6 or 12 channels, got %d", LC);
+  if (MODE == 0 && LC != 0 && LC != C) return set_error("feast: forward per-edge logits read the layer input");
   switch (C) {
-    case 6: GEOBI_AGG(6, 3); break;
-    case 12: GEOBI_AGG(12, 3); break;
-    case 32: GEOBI_AGG(32, 4); break;
-    case 64: GEOBI_AGG(64, 4); break;
-    case 128: GEOBI_AGG(128, 4); break;
+    case 6: if (MODE == 0) { if (LC) GEOBI_AGG(6, 3, 6); else GEOBI_AGG(6, 3, 0); } else GEOBI_AGG_L(6, 3); break;
+    case 12: if (MODE == 0) { if (LC) GEOBI_AGG(12, 3, 12); else GEOBI_AGG(12, 3, 0); } else GEOBI_AGG_L(12, 3); break;
+    case 32: if (MODE == 0) GEOBI_AGG(32, 4, 0); else GEOBI_AGG_L(32, 4); break;
+    case 64: if (MODE == 0) GEOBI_AGG(64, 4, 0); else GEOBI_AGG_L(64, 4); break;
+    case 128: if (MODE == 0) GEOBI_AGG(128, 4, 0); else GEOBI_AGG_L(128, 4); break;
     default: return set_error("feast: unsupported channel count %d (supported: 6, 12, 32, 64, 128)", C);
   }
+#undef GEOBI_AGG_L
 #undef GEOBI_AGG
   GEOBI_LAUNCH_OK();
   return 0;
@@ -486,19 +641,19 @@ int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const floa
 
 int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
                    const int* rowptr, const int* col, const float* dz, int ldz, int N, float* dl, float* dpn,
-                   float* dcs, int ld_dcs, hipStream_t s) {
-#define GEOBI_ROW(C_, V_)                                                                                     \
+                   float* dcs, int ld_dcs, int LC, const float* ul, hipStream_t s) {
+#define GEOBI_ROW(C_, V_, L_)                                                                                 \
   do {                                                                                                        \
     constexpr int NPW_ = 64 / (C_ / V_);                                                                      \
-    feast_rowpass_kernel<C_, V_><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
-                                                                   N, dl, dpn, dcs, ld_dcs);                  \
+    feast_rowpass_kernel<C_, V_, L_><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(                               \
+        xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, N, dl, dpn, dcs, ld_dcs, ul);                              \
   } while (0)
   switch (C) {
-    case 6: GEOBI_ROW(6, 3); break;
-    case 12: GEOBI_ROW(12, 3); break;
-    case 32: GEOBI_ROW(32, 4); break;
-    case 64: GEOBI_ROW(64, 4); break;
-    case 128: GEOBI_ROW(128, 4); break;
+    case 6: if (LC) GEOBI_ROW(6, 3, 6); else GEOBI_ROW(6, 3, 0); break;
+    case 12: if (LC) GEOBI_ROW(12, 3, 12); else GEOBI_ROW(12, 3, 0); break;
+    case 32: GEOBI_ROW(32, 4, 0); break;
+    case 64: GEOBI_ROW(64, 4, 0); break;
+    case 128: GEOBI_ROW(128, 4, 0); break;
     default: return set_error("feast: unsupported channel count %d", C);
   }
 #undef GEOBI_ROW
@@ -558,10 +713,11 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, wf);
   }
   GEOBI_LAUNCH_OK();
-  GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
+  const int LC = edge_logit_channels(Cin, Cb);      // level-0 layers: logits per edge from the raw rows, no p
+  if (LC == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
   prof_begin(PROF_AGG_FWD, s, feast_agg_bytes(N, Ecap, Cin, Kp), Cin);
   int rc = launch_aggregate<0>(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, p, cvec, rowptr_in, col_in, nullptr, (int)N, z,
-                               Kp, s);
+                               Kp, LC, xa, u_w, s);
   prof_end(PROF_AGG_FWD, s);
   GEOBI_TRY(rc);
   GemmEpilogue ep;
@@ -593,6 +749,10 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.tn_bytes = gemm_tn_ws_bytes(Kp + 1, Cout, N);           // [z | 1]^T g   (side stream)
   b.tn_ws = a.take<char>(b.tn_bytes);
   b.tn_bytes2 = gemm_tn_ws_bytes_any_width(2 * HP, Cin + 1, N);   // [dp | dcs]^T [x | 1], per input half
+  {                                                               // or the per-edge du / dc partials (level 0)
+    const size_t du_bytes = align_up((size_t)cdiv(N, 256) * (H * Cin + H) * sizeof(float)) + 256;
+    if ((Cin == 6 || Cin == 12) && du_bytes > b.tn_bytes2) b.tn_bytes2 = du_bytes;
+  }
   b.tn_ws2 = a.take<char>(b.tn_bytes2);
   size_t g1 = gemm_nn_ws_bytes(N, Kp), g2 = gemm_nn_ws_bytes(N, Cin);
   b.gemm_bytes = g1 > g2 ? g1 : g2;
@@ -651,8 +811,9 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_TRY(gemm_nn(g, Cout, wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
+  const int LC = edge_logit_channels(Cin, Cb);
   int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,
-                          b.rp + H * Cout + HP, ldr, s);
+                          b.rp + H * Cout + HP, ldr, LC, u_w, s);
   prof_end(PROF_ROWPASS, s);
   GEOBI_TRY(rc);
   // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
@@ -661,7 +822,21 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_LAUNCH_OK();
   // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]; needs the row
   //    pass and dp_gather only -> also off the critical path (side stream, after an event on main)
-  {
+  if (LC > 0) {
+    // per-edge du / dc (see feast_du_edge_kernel); needs dl and dcs only -> side stream as well
+    GEOBI_TRY(side_wait_main(fk, s));
+    hipStream_t ss = fk.side ? fk.side : s;
+    const int blocks = cdiv(N, 256);
+    float* partial = (float*)b.tn_ws2;
+    GEOBI_REQUIRE((size_t)blocks * (H * LC + H) * sizeof(float) <= b.tn_bytes2, "feast_bwd: du workspace too small");
+    if (LC == 6)
+      feast_du_edge_kernel<6><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, b.rp + H * Cout + HP, ldr, (int)N, partial);
+    else
+      feast_du_edge_kernel<12><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, b.rp + H * Cout + HP, ldr, (int)N, partial);
+    GEOBI_LAUNCH_OK();
+    feast_du_final_kernel<<<1, 128, 0, ss>>>(partial, blocks, LC, accumulate, du_w, dc);
+    GEOBI_LAUNCH_OK();
+  } else {
     GEOBI_TRY(side_wait_main(fk, s));
     hipStream_t ss = fk.side ? fk.side : s;
     TnOutput ou;
@@ -674,7 +849,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   }
   if (dxa != nullptr) {
     prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);
-    rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, s);
+    rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, LC, xa, u_w,
+                             s);
     prof_end(PROF_AGG_BWD, s);
     GEOBI_TRY(rc);
     const float* wp = wf_saved ? wf_saved + (size_t)Kp * Cout : b.wp;

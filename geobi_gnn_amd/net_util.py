@@ -352,8 +352,10 @@ def pool_face(cluster, fv_indices):
     return face[~invalid]
 
 
-def pooling(data, p_type='max', level=2, wei_type=0):
-    """net_util.py:305-343: on-the-fly pooling; returns (coarse Data, composed cluster index)."""
+def pooling(data, p_type='max', level=2, wei_type=0, graclus_fn=None):
+    """net_util.py:305-343: on-the-fly pooling; returns (coarse Data, composed cluster index).
+    graclus_fn (not in the reference): callable(edge_index, weight, num_nodes) -> cluster, used instead of the
+    built-in matching (parity tests replay the oracle's clusters through it, like PoolingLayer.graclus_fn)."""
     x, pos = data.x, getattr(data, 'pos', None)
     g = graph_of(data.edge_index, x.shape[0])
     if wei_type == 0:
@@ -366,8 +368,11 @@ def pooling(data, p_type='max', level=2, wei_type=0):
         w = _feature_gauss(x, g, 2)
     clusts = []
     for _ in range(level):
-        cnew, g_c, w_c, _, sidx = _coarsen(g, w)
+        given = None if graclus_fn is None else _i32(graclus_fn(g.coo64(), w, g.N))
+        cnew, g_c, w_c, cl_raw, sidx = _coarsen(g, w, given)
         clusts.append(cnew)
+        if sidx is None:          # injected clusters need not be a matching: general inverse lists
+            sidx = ops.SegmentIndex(cnew, g_c.N)
         x = _pool_features(x, sidx, p_type)
         pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
         g, w = g_c, w_c
@@ -376,8 +381,9 @@ def pooling(data, p_type='max', level=2, wei_type=0):
     return Data(x, g.coo64(), pos=pos, edge_weight=w), _compose(clusts).long()
 
 
-def pooling_pre(data, step=2, level=2):
-    """net_util.py:346-366: precompute the cluster hierarchy from the static edge weights."""
+def pooling_pre(data, step=2, level=2, graclus_fn=None):
+    """net_util.py:346-366: precompute the cluster hierarchy from the static edge weights
+    (graclus_fn: see `pooling`)."""
     n = data.num_nodes
     g = graph_of(data.edge_index, n)
     w = getattr(data, 'edge_weight', None)
@@ -385,7 +391,8 @@ def pooling_pre(data, step=2, level=2):
     for i in range(1, level + 1):
         clusters = []
         for _ in range(step):
-            cnew, g, w, _, _ = _coarsen(g, w)
+            given = None if graclus_fn is None else _i32(graclus_fn(g.coo64(), w, g.N))
+            cnew, g, w, _, _ = _coarsen(g, w, given)
             clusters.append(cnew.long())
         setattr(data, 'pool_l%d' % i, {'clusters': clusters, 'cluster_inv': _compose(clusters).long()})
     data.edge_weight = None

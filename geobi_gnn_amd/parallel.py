@@ -45,6 +45,42 @@ def shard_indices(num_items, rank, world, seed=0, epoch=0, shuffle=True):
     return order[rank::world]
 
 
+def rank_world():
+    """(rank, world size) of the default process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def owns_patch(k, rank, world):
+    """Inference on one large mesh across GPUs: patch k of the split (test_dual.py:53-58 runs them one
+    after the other) belongs to rank k mod world."""
+    return k % world == rank
+
+
+def reduce_patch_sums(tensors, dst=0):
+    """Sum the per-rank patch accumulators (Vp [V,3], Np [F,3], visit counts [V]) onto rank `dst`, in place there:
+    the one collective of multi-GPU inference.  The buffers are packed into one fp32 message (counts are small
+    integers, exact in fp32) so a mesh costs one reduction, not three."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    if flat.is_cuda and dist.get_backend() == 'gloo':
+        # rehearsal of the multi-rank path on one device (GEOBI_DIST_BACKEND=gloo): gloo has no device-side reduce
+        host = flat.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        flat = host.to(flat.device)
+    else:
+        dist.reduce(flat, dst=dst, op=dist.ReduceOp.SUM)       # RCCL over xGMI
+    if dist.get_rank() == dst:
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+            off += n
+    return tensors
+
+
 class GradBucket(object):
     """All parameter gradients as views of one flat fp32 buffer: zeroing is one memset, the
     data-parallel reduction is one all-reduce, and nothing is copied in or out."""

@@ -45,9 +45,12 @@ def submesh(fv, sel, num_vertices):
     return v_idx[:L.read_i32(count, 1)[0]], f_sub
 
 
-def split_patches(points, fv, submesh_size, incidence=None):
+def split_patches(points, fv, submesh_size, incidence=None, keep=None):
     """Generator over the patches of dataset.py:156-193: yields (select_faces, V_idx, F_sub) device int32
-    tensors.  points [V,3] fp32 and fv [F,3] int32 live on the device."""
+    tensors.  points [V,3] fp32 and fv [F,3] int32 live on the device.
+    keep: optional callable(k) -> bool.  Patch k is still grown (the next seed depends on every earlier patch) but
+    when keep(k) is false nothing is built on the device and None is yielded -- how the ranks of a multi-GPU
+    inference each take their share of one mesh's patches."""
     V, F = points.shape[0], fv.shape[0]
     rowptr, lst = incidence if incidence is not None else meshprep.vertex_faces(fv, V)
     fv_h = fv.cpu().numpy()
@@ -57,12 +60,17 @@ def split_patches(points, fv, submesh_size, incidence=None):
     d2 = ((face_cent - centroid) ** 2).sum(1).cpu().numpy()
     flag = np.zeros(F, dtype=bool)
     seed = int(np.argmax(d2))
+    k = 0
     while True:
         sel_h = patch_grow(fv_h, rp_h, ls_h, seed, neighbor_count=submesh_size)
         flag[sel_h] = True
-        sel = torch.from_numpy(sel_h).to(fv.device)
-        v_idx, f_sub = submesh(fv, sel, V)
-        yield sel, v_idx, f_sub
+        if keep is None or keep(k):
+            sel = torch.from_numpy(sel_h).to(fv.device)
+            v_idx, f_sub = submesh(fv, sel, V)
+            yield sel, v_idx, f_sub
+        else:
+            yield None
+        k += 1
         left = np.where(~flag)[0]
         if left.size == 0:
             break
@@ -78,13 +86,22 @@ def _union_dual(duals):
     return (data_v, data_f), list(zip(pv[:-1], pv[1:])), list(zip(pf[:-1], pf[1:]))
 
 
-def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=8):
+def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=8,
+                 distributed=None):
     """test_dual.py:24-87 without the OBJ IO, for a mesh of any size: preprocessing, patch split when
     F > sub_size, network, merge, de-normalisation, vertex update -- all device-resident.  The reference runs
     the patches one by one; here `patch_batch` of them go through the network as one disjoint-union graph
     (independent components: same results, fewer and better-filled launches).
 
+    Multi-GPU: with torch.distributed initialised (``distributed=None`` picks that up; False turns it
+    off) every rank calls this with the same mesh; the patches are dealt round-robin over the ranks
+    (parallel.owns_patch), each rank merges its own into its Vp / Np / visit-count sums, ONE reduction to rank 0
+    (parallel.reduce_patch_sums) adds them, and rank 0 finalises and runs the vertex update.  No graph is split
+    across GPUs and nothing but those three sums crosses xGMI.  Other ranks get Vp = Np = V_updated = None.
+
     Returns dict(Vp, Np, V_updated, n_patches, angle1, angle2)."""
+    from . import parallel
+    rank, world = parallel.rank_world() if distributed is None or distributed else (0, 1)
     dev = next(net.parameters()).device
     pts = torch.as_tensor(np.asarray(points) if not torch.is_tensor(points) else points)
     pts = pts.to(device=dev, dtype=torch.float32).contiguous()
@@ -97,10 +114,12 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     scale = float((1.0 / meshprep.mean_edge_length(pts, g_v)).item())
 
     if F <= sub_size:
+        n_patches = 1
+        if rank != 0:                  # one patch: nothing to share out
+            return {'Vp': None, 'Np': None, 'V_updated': None, 'n_patches': 1, 'angle1': None, 'angle2': None}
         dual = meshprep.build_dual_data(pts, fv, name='mesh', data_type=data_type, device=dev)
         Vp, Np = predict_one_submesh(net, dual)
         Vp = Vp / scale + centroid
-        n_patches = 1
     else:
         Vp = torch.zeros((V, 3), dtype=torch.float32, device=dev)
         Np = torch.zeros((F, 3), dtype=torch.float32, device=dev)
@@ -121,14 +140,23 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
                        v_idx.shape[0], sel.shape[0], L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), L.stream())
             del pending[:]
 
-        for sel, v_idx, f_sub in split_patches(pts, fv, sub_size, incidence=(rowptr, lst)):
-            dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, name='patch%d' % n_patches, data_type=data_type,
-                                            device=dev, centroid=centroid, scale=scale)
-            pending.append((sel, v_idx, dual))
+        keep = None if world == 1 else (lambda k: parallel.owns_patch(k, rank, world))
+        for part in split_patches(pts, fv, sub_size, incidence=(rowptr, lst), keep=keep):
             n_patches += 1
+            if part is None:
+                continue
+            sel, v_idx, f_sub = part
+            dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, name='patch%d' % (n_patches - 1),
+                                            data_type=data_type, device=dev, centroid=centroid, scale=scale)
+            pending.append((sel, v_idx, dual))
             if len(pending) >= max(1, int(patch_batch)):
                 flush()
         flush()
+        if world > 1:
+            parallel.reduce_patch_sums([Vp, Np, sum_v], dst=0)
+            if rank != 0:
+                return {'Vp': None, 'Np': None, 'V_updated': None, 'n_patches': n_patches, 'angle1': None,
+                        'angle2': None}
         c = centroid.reshape(-1).tolist()
         L.call('geobi_patch_finalize', L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), V, F, scale, c[0], c[1], c[2], L.stream())
 

@@ -1,0 +1,47 @@
+"""bench.py's contract on the GPU box: the single-GPU line carries every field the driver reads, and
+`python bench.py --gpus 2` from a bare shell starts its own two ranks (on a 1-GPU box: both on device 0 over
+gloo, labelled as a rehearsal)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv):
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, text=True,
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu():
+    out = _bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline')
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and out['warmup'] == 1
+    assert out['unit'] == 'M-edges/s' and out['value'] > 0 and out['higher_is_better'] is True
+    assert out['scaling'] == 'weak' and out['dtype'] == 'f32' and out['vs_baseline'] is None
+    assert abs(out['ms_per_step'] * out['value'] - out['config']['edges_per_rank_step'] / 1e3) < 1e-2 * out['config']['edges_per_rank_step'] / 1e3
+    roof = out['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+
+
+def test_bench_two_ranks_from_a_bare_shell():
+    assert torch.cuda.is_available()
+    out = _bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--no-roofline', '--no-cpu-baseline')
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2'
+    assert out['config']['edges_per_rank_step'] == 1351448
+    if torch.cuda.device_count() < 2:
+        assert 'rehearsal' in out['config'] and 'gloo' in out['config']['collective']
+    else:
+        assert 'rehearsal' not in out['config'] and 'nccl' in out['config']['collective']

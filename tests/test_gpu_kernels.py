@@ -103,14 +103,16 @@ def test_gemm_tn(dev, M, I, J):
 
 
 # ------------------------------------------------------------------------- FeaSt conv
-def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0):
+def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0, x=None):
     from geobi_gnn_amd.feast_conv import FeaStConv
     from oracle import pyg_ops as P
     torch.manual_seed(seed)
     ora = P.FeaStConv(Cin, Cout, 9).double()
     hip = FeaStConv(Cin, Cout, 9).to(dev)
     hip.load_state_dict({k: v.float() for k, v in ora.state_dict().items()})
-    x = torch.randn(n, Cin, dtype=torch.double) * xscale
+    if x is None:
+        x = torch.randn(n, Cin, dtype=torch.double) * xscale
+    x = x.double()
     gout = torch.randn(n, Cout, dtype=torch.double)
     xo = x.clone().requires_grad_(True)
     out_o = ora(xo, ei)
@@ -162,7 +164,39 @@ def test_feast_conv_large_logits(dev):
     n = 500
     ei = _sym_graph(n, 2000, seed=5)
     errs = _run_feast(dev, 12, 32, ei, n, 0.2, False, seed=5, xscale=30.0)
-    assert max(errs.values()) < 5e-5, errs      # logits ~1e2: fp32 p_j - p_i cancellation dominates
+    assert max(errs.values()) < TOL, errs       # 6- / 12-channel layers evaluate u (x_j - x_i) per edge, like the reference
+
+
+@pytest.mark.parametrize('which', ['vertex', 'facet'])
+def test_feast_conv_level0_coordinates_far_from_origin(dev, which):
+    """Level-0 inputs as the dataset delivers them for a patch of a large scan: positions in units of the mean
+    edge length around the WHOLE mesh's centroid (dataset.py:140,179), i.e. coordinates of several hundred with
+    neighbours ~1 apart.  Output and every gradient (u.weight included) stay within 1e-5 of the fp64 oracle."""
+    from geobi_gnn_amd import meshgen
+    dv, df = meshgen.synthetic_dual_data(8, 0.2, seed=2)
+    d = dv if which == 'vertex' else df
+    x = d.x.clone()
+    x[:, :3] += torch.tensor([310.0, -205.0, 97.0])
+    if which == 'facet':      # the facet branch's l_conv1 reads 12 channels: [x_f | centroid | normal]
+        x = torch.cat([x, x[:, :3] + 0.01, x[:, 3:]], 1)
+    errs = _run_feast(dev, x.shape[1], 32, d.edge_index, x.shape[0], 0.2, False, seed=3, x=x)
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize('which', ['vertex', 'facet'])
+def test_feast_conv_level0_at_large_scan_size(dev, which):
+    """l_conv1 (Cin 6 / 12 -> 32) on the level-0 graphs of BASELINE configs[3] (n = 87: V = 75 692, F = 151 380,
+    1.97 M facet edges, |x| up to ~72): output and all gradients vs the fp64 oracle at 1e-5."""
+    from geobi_gnn_amd import meshgen
+    torch.set_num_threads(16)
+    dv, df = meshgen.synthetic_dual_data(87, 0.2, seed=7)
+    d = dv if which == 'vertex' else df
+    x = d.x.clone()
+    if which == 'facet':      # [x_f | centroid | normal] as network.py:335-337 assembles it (here from the input geometry)
+        x = torch.cat([x, x[:, :3], x[:, 3:]], 1)
+    errs = _run_feast(dev, x.shape[1], 32, d.edge_index, x.shape[0], 0.2, False, seed=4, x=x)
+    print(which, errs)
+    assert max(errs.values()) < TOL, errs
 
 
 def test_feast_conv_deterministic(dev):

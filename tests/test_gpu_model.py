@@ -169,14 +169,18 @@ def test_state_dict_compat_pyg1_names(dev):
 
 
 def test_full_size_properties(dev):
-    """n = 32 (F = 20 480), union of 2 meshes: determinism, per-mesh independence, finite grads."""
+    """BASELINE configs[2] exactly as bench.py runs it: the disjoint union of 4 meshes of n = 32 (F = 20 480 each,
+    1 351 448 level-0 edges) -- determinism, per-mesh independence, per-mesh gradient accumulation, finite grads."""
     from geobi_gnn_amd import network, meshgen
     from geobi_gnn_amd.data import union_batch
+    from geobi_gnn_amd.parallel import batched_losses
     torch.manual_seed(0)
     net = network.DualGNN().to(dev)
-    a = meshgen.synthetic_dual_data(32, 0.2, seed=200)
-    b = meshgen.synthetic_dual_data(32, 0.3, seed=201)
+    sig = (0.1, 0.2, 0.3)
+    meshes = [meshgen.synthetic_dual_data(32, sig[i % 3], seed=200 + i) for i in range(4)]      # bench.make_batch, rank 0
+    a, b = meshes[0], meshes[1]
     assert a[0].edge_index.shape[1] + a[1].edge_index.shape[1] == 337862       # BASELINE.md edge count
+    assert sum(m[0].edge_index.shape[1] + m[1].edge_index.shape[1] for m in meshes) == 1351448
 
     def run(pairs):
         dv, df = union_batch(pairs)
@@ -188,15 +192,32 @@ def test_full_size_properties(dev):
         g = torch.cat([p.grad.flatten() for p in net.parameters()])
         return vp.detach(), npred.detach(), g.clone()
 
-    v_ab, n_ab, g_ab = run([a, b])
-    v_ab2, n_ab2, g_ab2 = run([a, b])
+    v_ab, n_ab, g_ab = run(meshes)
+    v_ab2, n_ab2, g_ab2 = run(meshes)
     assert torch.equal(v_ab, v_ab2) and torch.equal(n_ab, n_ab2) and torch.equal(g_ab, g_ab2)   # bitwise
     assert bool(torch.isfinite(g_ab).all()) and float(g_ab.abs().max()) > 0
     assert bool(((n_ab.norm(dim=1) - 1).abs() < 1e-5).all())                                     # unit normals
     # a mesh's prediction does not depend on what it is batched with (disjoint union, no cross edges)
-    v_a, n_a, _ = run([a])
     V, F = a[0].x.shape[0], a[1].x.shape[0]
-    assert torch.equal(v_ab[:V], v_a) and torch.equal(n_ab[:F], n_a)
+    for k in (0, 3):
+        v_k, n_k, _ = run([meshes[k]])
+        assert torch.equal(v_ab[k * V:(k + 1) * V], v_k) and torch.equal(n_ab[k * F:(k + 1) * F], n_k)
+    # per-mesh mean losses over the union == the reference's accumulation of loss / batch_size over single-mesh
+    # steps (train_dual.py:204-218): same gradient up to fp32 summation order
+    dv, df = union_batch(meshes)
+    dv, df = dv.to(dev), df.to(dev)
+    net.zero_grad()
+    vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+    lv, ln = batched_losses(vp, npred, dv, df, 'L1', 'L1')
+    network.dual_loss(lv, ln).backward()
+    g_union = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+    net.zero_grad()
+    for m in meshes:
+        mv, mf = m[0].to(dev), m[1].to(dev)
+        vp, npred, _ = net((mv.shallow_copy(), mf.shallow_copy()))
+        (network.dual_loss(network.loss_v(vp, mv.y, 'L1'), network.loss_n(npred, mf.y, 'L1')) / 4).backward()
+    g_acc = torch.cat([p.grad.flatten() for p in net.parameters()])
+    assert rel_err(g_union, g_acc) < 1e-5
 
 
 def test_training_reduces_loss(dev):
@@ -253,6 +274,34 @@ def test_large_scan_inference(dev):
     assert 0.0 <= r1['angle1'] <= 180.0 and 0.0 <= r1['angle2'] <= 180.0
     # the input bags were not consumed by the forward (shallow copies)
     assert dvd.x.shape[1] == 6 and dfd.x.shape[1] == 6
+
+
+def test_large_scan_forward_against_fp64_oracle(dev):
+    """BASELINE configs[3] (n = 87, F = 151 380, level-0 coordinates up to ~72): forward parity of the whole network
+    against the fp64 oracle with the HIP path's clusters replayed (the one size never checked)."""
+    from geobi_gnn_amd import network, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    from oracle.weights import make_state_dict
+    torch.set_num_threads(16)
+    sd = make_state_dict(R.DualGNN().state_dict(), 6)
+    net = _hip_net(sd, dev).eval()
+    dv, df = meshgen.synthetic_dual_data(87, 0.2, seed=7)
+    assert float(dv.x[:, :3].abs().max()) > 60.0
+    with torch.no_grad():
+        vp, npred, _ = net((dv.to(dev), df.to(dev)))
+    raw = []
+    for m in (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2):
+        raw += [c.cpu() for c in m.last_clusters]
+    ora = R.DualGNN().double()
+    ora.load_state_dict({k: v.double() for k, v in sd.items()})
+    install_replay(ora, raw)
+    a = P.Data(dv.x.double(), dv.edge_index.clone(), edge_weight=dv.edge_weight.double())
+    b = P.Data(df.x.double(), df.edge_index.clone(), edge_weight=df.edge_weight.double(), fv_indices=df.fv_indices.clone())
+    with torch.no_grad():
+        vo, no, _ = ora((a, b))
+    ev, en = rel_err(vp.cpu(), vo), float((npred.cpu().double() - no).abs().max())
+    print('n=87 forward vs fp64 oracle: verts %.2e (of max %.1f), normals %.2e' % (ev, float(vo.abs().max()), en))
+    assert ev < OUT_TOL and en < OUT_TOL
 
 
 def test_angular_error_statistical_parity(dev):
@@ -575,3 +624,209 @@ def test_pooling_layer_other_step_counts_against_oracle(dev, pool_step, pool_typ
     layer_h.unpooling(out.x).backward(g.to(dev))
     layer_o.unpooling(ref.x).backward(g)
     assert rel_err(xh.grad.cpu(), xo.grad) < 1e-6
+
+
+@pytest.mark.parametrize('p_type,wei_type', [('max', 0), ('mean', 0), ('max', 1), ('max', 2)])
+def test_functional_pooling_against_oracle(dev, p_type, wei_type):
+    """net_util.pooling (net_util.py:305-343) vs oracle/ref_model.pooling: the oracle runs its seeded graclus, the
+    recorded clusters are replayed on the HIP side -- pooled features, positions, coarse edges + mean weights and the
+    composed cluster index must agree (a14 was only self-compared)."""
+    from geobi_gnn_amd import net_util, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    dv, _ = meshgen.synthetic_dual_data(9, 0.2, seed=21)
+    torch.manual_seed(wei_type)
+    feat = torch.randn(dv.x.shape[0], 16) * 0.5
+    pos = dv.x[:, :3].clone()
+    rec = []
+
+    def graclus_rec(ei, w=None, n=None):
+        c = P.graclus(ei, w, n, generator=torch.Generator().manual_seed(100 + len(rec)))
+        rec.append(c.clone())
+        return c
+    do = P.Data(feat.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone(), pos=pos.clone())
+    ref, inv_o = R.pooling(do, p_type, level=2, wei_type=wei_type, graclus_fn=graclus_rec)
+    assert len(rec) == 2
+    it = iter(rec)
+    dh = dv.to(dev)
+    dh.x, dh.pos = feat.to(dev), pos.to(dev)
+    out, inv_h = net_util.pooling(dh, p_type, level=2, wei_type=wei_type, graclus_fn=lambda ei, w=None, n=None: next(it).to(dev))
+    assert torch.equal(inv_h.cpu(), inv_o)
+    assert rel_err(out.x.cpu(), ref.x) < 1e-6 and rel_err(out.pos.cpu(), ref.pos) < 1e-6
+    nc = ref.x.shape[0]
+    kh, wh = _edge_map(out.edge_index, out.edge_weight, nc)
+    ko, wo = _edge_map(ref.edge_index, ref.edge_weight, nc)
+    assert torch.equal(kh, ko) and rel_err(wh, wo.double()) < 1e-5
+
+
+def test_pooling_pre_and_run_against_oracle(dev):
+    """net_util.pooling_pre / pooling_run (net_util.py:346-380) vs the oracle: same cluster hierarchy from replayed
+    graclus outputs, and the replay of that hierarchy gives the oracle's features / positions / edges."""
+    from geobi_gnn_amd import net_util, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    dv, _ = meshgen.synthetic_dual_data(9, 0.3, seed=22)
+    torch.manual_seed(2)
+    feat = torch.randn(dv.x.shape[0], 8)
+    pos = dv.x[:, :3].clone()
+    rec = []
+
+    def graclus_rec(ei, w=None, n=None):
+        c = P.graclus(ei, w, n, generator=torch.Generator().manual_seed(7 + len(rec)))
+        rec.append(c.clone())
+        return c
+    pre_o = R.pooling_pre(P.Data(feat.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone()),
+                          step=2, level=2, graclus_fn=graclus_rec)
+    assert len(rec) == 4 and pre_o.edge_weight is None
+    it = iter(rec)
+    dh = dv.to(dev)
+    dh.x = feat.to(dev)
+    pre_h = net_util.pooling_pre(dh, step=2, level=2, graclus_fn=lambda ei, w=None, n=None: next(it).to(dev))
+    assert pre_h.edge_weight is None
+    for lvl in ('pool_l1', 'pool_l2'):
+        ho, hh = getattr(pre_o, lvl), getattr(pre_h, lvl)
+        assert len(ho['clusters']) == len(hh['clusters']) == 2
+        for co, ch in zip(ho['clusters'], hh['clusters']):
+            assert torch.equal(ch.cpu(), co)
+        assert torch.equal(hh['cluster_inv'].cpu(), ho['cluster_inv'])
+    for p_type in ('max', 'mean'):
+        run_o = R.pooling_run(P.Data(feat.clone(), dv.edge_index.clone(), pos=pos.clone()), pre_o.pool_l1, p_type)
+        dr = dv.to(dev)
+        dr.x, dr.pos = feat.to(dev), pos.to(dev)
+        run_h = net_util.pooling_run(dr, {'clusters': [c.to(dev) for c in pre_o.pool_l1['clusters']]}, p_type)
+        assert rel_err(run_h.x.cpu(), run_o.x) < 1e-6 and rel_err(run_h.pos.cpu(), run_o.pos) < 1e-6
+        nc = run_o.x.shape[0]
+        key = lambda ei: torch.sort((ei[0] * nc + ei[1]).cpu())[0]
+        assert torch.equal(key(run_h.edge_index), key(run_o.edge_index))
+
+
+def _matching_stats(log, n0, n_out):
+    """per step: matched-node fraction and matched share of the total edge weight; overall coarsening ratio."""
+    return ([s['matched'] for s in log], [s['wsum'] / s['wtot'] for s in log], n_out / float(n0))
+
+
+def _logged(fn, log):
+    def wrapped(ei, w=None, n=None):
+        c = fn(ei, w, n)
+        row, col = ei[0].cpu(), ei[1].cpu()
+        cc, ww = c.cpu(), w.detach().cpu().double()
+        und = row < col
+        pair = (cc[row] == cc[col]) & und
+        log.append({'matched': 2.0 * int(pair.sum()) / n, 'wsum': float(ww[pair].sum()), 'wtot': float(ww[und].sum())})
+        return c
+    return wrapped
+
+
+@pytest.mark.parametrize('which', ['vertex', 'facet'])
+def test_matching_statistics_vs_oracle_graclus_at_bench_size(dev, which):
+    """a6 (net_util.py:127): the HIP matching is deterministic greedy heavy-edge matching, torch_cluster's graclus a
+    randomised greedy one.  At the benchmark's mesh size (n = 32) and with the network's weight type 10, over 20
+    graclus seeds: matched-node fraction, matched share of the edge weight and the node ratios after pooling1 (level
+    1) and pooling2 (level 2) of the HIP matching must lie within the stated bands of the oracle's mean -- bands =
+    2-3x the oracle's own seed-to-seed spread (measured: matched fraction +-0.007, weight share +-1 %, ratios +-1 %).
+    SURVEY 8 quotes ~0.29 / 0.09 (vertex) and ~0.27 / 0.074 (facet) for the node ratios."""
+    from geobi_gnn_amd import net_util, meshgen
+    from oracle import ref_model as R, pyg_ops as P
+    torch.set_num_threads(8)
+    dv, df = meshgen.synthetic_dual_data(32, 0.2, seed=300)
+    d = dv if which == 'vertex' else df
+    n0 = d.x.shape[0]
+
+    def hip_run():
+        log = []
+        l1, l2 = net_util.PoolingLayer(6, 'max', 2, 10).to(dev), net_util.PoolingLayer(6, 'max', 2, 10).to(dev)
+        # graclus_fn left unset: the built-in matching runs; the raw clusters are read back afterwards
+        dd = d.to(dev)
+        o1 = l1(dd)
+        o2 = l2(o1)
+        return l1, l2, dd, o1, o2
+
+    l1, l2, dd, o1, o2 = hip_run()
+    # replay the HIP clusters through the logging wrapper on the oracle layers to get the same statistics
+    hip_log = []
+    it = iter([c.cpu() for c in l1.last_clusters + l2.last_clusters])
+    r1, r2 = R.PoolingLayer(6, 'max', 2, 10), R.PoolingLayer(6, 'max', 2, 10)
+    r1.graclus_fn = r2.graclus_fn = _logged(lambda ei, w, n: next(it), hip_log)
+    q1 = r1(P.Data(d.x.clone(), d.edge_index.clone(), edge_weight=d.edge_weight.clone()))
+    q2 = r2(q1)
+    assert q1.x.shape[0] == o1.x.shape[0] and q2.x.shape[0] == o2.x.shape[0]
+    hm, hw, _ = _matching_stats(hip_log, n0, q2.x.shape[0])
+    h_ratio1, h_ratio2 = q1.x.shape[0] / n0, q2.x.shape[0] / n0
+
+    om, ow, o_r1, o_r2 = [], [], [], []
+    for seed in range(20):
+        log = []
+        gen = torch.Generator().manual_seed(1000 + seed)
+        g1, g2 = R.PoolingLayer(6, 'max', 2, 10), R.PoolingLayer(6, 'max', 2, 10)
+        g1.graclus_fn = g2.graclus_fn = _logged(lambda ei, w, n: P.graclus(ei, w, n, generator=gen), log)
+        a1 = g1(P.Data(d.x.clone(), d.edge_index.clone(), edge_weight=d.edge_weight.clone()))
+        a2 = g2(a1)
+        m, w, _ = _matching_stats(log, n0, a2.x.shape[0])
+        om.append(m); ow.append(w); o_r1.append(a1.x.shape[0] / n0); o_r2.append(a2.x.shape[0] / n0)
+    om, ow = np.array(om), np.array(ow)
+    print('%s n0=%d  ratio L1 hip %.4f oracle %.4f [%.4f, %.4f]   L2 hip %.4f oracle %.4f [%.4f, %.4f]' %
+          (which, n0, h_ratio1, np.mean(o_r1), min(o_r1), max(o_r1), h_ratio2, np.mean(o_r2), min(o_r2), max(o_r2)))
+    for s in range(4):
+        print('  step %d matched hip %.4f oracle %.4f +- %.4f   weight share hip %.4f oracle %.4f +- %.4f' %
+              (s, hm[s], om[:, s].mean(), om[:, s].std(), hw[s], ow[:, s].mean(), ow[:, s].std()))
+        assert abs(hm[s] - om[:, s].mean()) <= 0.02, (s, hm[s], om[:, s].mean())
+        assert abs(hw[s] - ow[:, s].mean()) <= 0.04 * ow[:, s].mean(), (s, hw[s], ow[:, s].mean())
+    assert abs(h_ratio1 - np.mean(o_r1)) <= 0.03 * np.mean(o_r1)
+    assert abs(h_ratio2 - np.mean(o_r2)) <= 0.05 * np.mean(o_r2)
+    lo1, hi1, lo2, hi2 = (0.27, 0.31, 0.08, 0.10) if which == 'vertex' else (0.255, 0.29, 0.068, 0.085)
+    assert lo1 <= h_ratio1 <= hi1 and lo2 <= h_ratio2 <= hi2, (h_ratio1, h_ratio2)
+
+
+def test_angular_error_parity_at_bench_size(dev):
+    """SURVEY 8d metric 2 at the benchmark's mesh size: a network trained for 240 steps at n = 32 (on the device, inside
+    this test) is evaluated on unseen meshes by the HIP path (own deterministic matching) and by the CPU oracle (seeded
+    graclus, 3 seeds per mesh).  The face-count-weighted mean angular errors vs ground truth must agree within 2 %
+    relative, or within the oracle's own seed-to-seed range if that is wider."""
+    from geobi_gnn_amd import network, meshgen
+    from geobi_gnn_amd.data import union_batch_graphs
+    from geobi_gnn_amd.parallel import FlatParameters, batched_losses
+    from oracle import ref_model as R, pyg_ops as P
+    torch.set_num_threads(16)
+    torch.manual_seed(5)
+    net = network.DualGNN().to(dev)
+    flat = FlatParameters(net)
+    opt = torch.optim.Adam(flat.parameters(), lr=2e-3)
+    sig = (0.1, 0.2, 0.3)
+    train = [tuple(t.to(dev) for t in meshgen.synthetic_dual_data(32, sig[i % 3], seed=700 + i)) for i in range(6)]
+    for a, b in train:
+        a.graph(); b.graph()
+    for step in range(240):
+        pick = [train[(2 * step + k) % 6] for k in range(2)]
+        dv, df = union_batch_graphs(pick)
+        flat.bucket.zero()
+        vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+        lv, ln = batched_losses(vp, npred, dv, df, 'L1', 'L1')
+        network.dual_loss(lv, ln).backward()
+        opt.step()
+        if step == 160:
+            for g in opt.param_groups:
+                g['lr'] = 5e-4
+    net.eval()
+    ora = R.DualGNN()
+    ora.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    tot_h, cnt = 0.0, 0.0
+    tot_o = [0.0, 0.0, 0.0]
+    for i, s in enumerate((0.1, 0.2, 0.3)):
+        dv, df = meshgen.synthetic_dual_data(32, s, seed=900 + i)
+        F_ = df.y.shape[0]
+        with torch.no_grad():
+            _, nh, _ = net((dv.to(dev), df.to(dev)))
+            tot_h += network.error_n(nh, df.y.to(dev)).item() * F_
+            for k in range(3):
+                torch.manual_seed(40 + 10 * i + k)               # graclus draws its visiting order from the global RNG
+                a = P.Data(dv.x.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone())
+                b = P.Data(df.x.clone(), df.edge_index.clone(), edge_weight=df.edge_weight.clone(),
+                           fv_indices=df.fv_indices.clone())
+                _, no, _ = ora((a, b))
+                tot_o[k] += R.error_n(no, df.y).item() * F_
+        cnt += F_
+    err_h = tot_h / cnt
+    errs_o = [t / cnt for t in tot_o]
+    mean_o = sum(errs_o) / 3
+    print('n=32 mean angular error: HIP %.4f deg; oracle %s (mean %.4f)' % (err_h, ['%.4f' % e for e in errs_o], mean_o))
+    assert mean_o < 10.0 and err_h < 10.0                       # training brought both far below the untrained ~90 deg
+    slack = max(0.02 * mean_o, max(errs_o) - min(errs_o))
+    assert abs(err_h - mean_o) <= slack, (err_h, errs_o)

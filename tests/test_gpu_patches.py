@@ -81,3 +81,145 @@ def test_predict_mesh_merges_like_the_reference(dev):
     # a mesh that fits one pass takes the single-patch branch
     one = patches.predict_mesh(net, pts, fv, sub_size=F, n_iter=5)
     assert one['n_patches'] == 1 and one['Np'].shape == (F, 3)
+
+
+def _c2_mesh(i):
+    """Mesh i of the stand-in for dataset/Synthetic/test_list.txt (tools/test_synthetic.py)."""
+    from geobi_gnn_amd import meshgen
+    n, sg = (16, 22, 32, 45)[i % 4], (0.1, 0.2, 0.3)[i % 3]
+    return n, meshgen.noisy_icosphere(n, sg, seed=100 + i)
+
+
+@pytest.mark.parametrize('i', [3, 7])
+def test_c2_full_size_patch_split(dev, i):
+    """BASELINE configs[1], the meshes of the test list that exceed one patch: n = 45 (F = 40 500) split at the
+    reference's sub_size = 20000 (test_dual.py:158).  Patches through the network 8 per pass or one by one give the
+    same bits; the device merge equals a torch restatement of test_dual.py:49-61; the split is a cover of the mesh
+    by patches of exactly sub_size faces (dataset.py:156-193)."""
+    from geobi_gnn_amd import meshprep, network, patches
+    from geobi_gnn_amd.infer import predict_one_submesh
+    n, (noisy, clean, faces) = _c2_mesh(i)
+    assert n == 45 and faces.shape[0] == 40500
+    pts = torch.from_numpy(noisy).to(dev)
+    fv = torch.from_numpy(faces).to(dev).int().contiguous()
+    V, F = pts.shape[0], fv.shape[0]
+    torch.manual_seed(0)
+    net = network.DualGNN().to(dev).eval()
+    out = patches.predict_mesh(net, pts, fv, sub_size=20000, n_iter=60, gt_points=clean)
+    one = patches.predict_mesh(net, pts, fv, sub_size=20000, n_iter=60, patch_batch=1)
+    assert out['n_patches'] == one['n_patches'] >= 3
+    assert torch.equal(out['Np'], one['Np']) and torch.equal(out['Vp'], one['Vp'])
+    assert torch.equal(out['V_updated'], one['V_updated'])
+
+    parts = list(patches.split_patches(pts, fv, 20000))
+    assert len(parts) == out['n_patches']
+    covered = torch.zeros(F, dtype=torch.int32, device=dev)
+    for sel, v_idx, f_sub in parts:
+        assert sel.shape[0] == 20000 and int(torch.unique(sel).shape[0]) == 20000
+        covered[sel.long()] += 1
+        assert torch.equal(v_idx.long()[f_sub.long()], fv.long()[sel.long()])      # renumbering maps back
+    assert int(covered.min()) >= 1 and int(covered.max()) > 1                      # a cover, with overlap
+
+    rowptr, lst = meshprep.vertex_faces(fv, V)
+    g_v = meshprep.ring_graph(0, fv, rowptr, lst, V)
+    centroid = pts.mean(0, keepdim=True)
+    scale = float((1.0 / meshprep.mean_edge_length(pts, g_v)).item())
+    sum_v = torch.zeros((V, 1), device=dev)
+    Vp = torch.zeros((V, 3), device=dev)
+    Np = torch.zeros((F, 3), device=dev)
+    for sel, v_idx, f_sub in parts:
+        dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, device=dev, centroid=centroid, scale=scale)
+        vert_p, norm_p = predict_one_submesh(net, dual)
+        sum_v[v_idx.long()] += 1
+        Vp[v_idx.long()] += vert_p
+        Np[sel.long()] += norm_p
+    Vp = Vp / sum_v / scale + centroid
+    Np = torch.nn.functional.normalize(Np, dim=1)
+    assert float((out['Vp'] - Vp).abs().max()) <= 1e-5 * float(Vp.abs().max())
+    assert float((out['Np'] - Np).abs().max()) <= 1e-5
+    assert torch.isfinite(out['V_updated']).all() and 0.0 <= out['angle1'] <= 180.0 and 0.0 <= out['angle2'] <= 180.0
+
+
+@pytest.mark.parametrize('i', [0, 1])
+def test_c2_single_patch_meshes_against_oracle(dev, i):
+    """BASELINE configs[1], meshes that fit one patch (n = 16, 22): the whole inference chain of test_dual.py:24-87
+    -- device preprocessing, network, de-normalisation, 60-sweep vertex update, both angular errors -- element-wise
+    against the CPU oracle run on the reference-layout tensors with the HIP path's clusters replayed."""
+    from geobi_gnn_amd import meshprep, network, patches
+    from oracle import ref_model as R, pyg_ops as P
+    from oracle.weights import make_state_dict
+    from helpers import install_replay, rel_err
+    n, (noisy, clean, faces) = _c2_mesh(i)
+    sd = make_state_dict(R.DualGNN().state_dict(), 12 + i)
+    net = network.DualGNN().to(dev)
+    net.load_state_dict(sd)
+    net.eval()
+    out = patches.predict_mesh(net, noisy, faces, sub_size=20000, n_iter=60, gt_points=clean)
+    assert out['n_patches'] == 1
+    raw = []
+    for m in (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2):
+        raw += [c.cpu() for c in m.last_clusters]
+    # the oracle reads what the reference's loader would hand over (COO with self loops, loop weights included)
+    dv, df = meshprep.build_dual_data(noisy, faces, device=dev, reference_layout=True)
+    a = P.Data(dv.x.cpu(), dv.edge_index.cpu(), edge_weight=dv.edge_weight.cpu())
+    b = P.Data(df.x.cpu(), df.edge_index.cpu(), edge_weight=df.edge_weight.cpu(), fv_indices=df.fv_indices.cpu())
+    ora = R.DualGNN()
+    ora.load_state_dict(sd)
+    install_replay(ora, raw)
+    with torch.no_grad():
+        vo, no, _ = ora((a, b))
+    cen, scale = dv.meta['centroid'].cpu(), dv.meta['scale']
+    Vo = vo / scale + cen
+    assert rel_err(out['Vp'].cpu(), Vo) < 1e-5
+    assert float((out['Np'].cpu() - no).abs().max()) < 1e-5
+    fv64 = torch.from_numpy(faces).long()
+    Vu = R.update_position2(Vo, fv64, dv.meta['vf_indices'].cpu(), no, n_iter=60)
+    assert rel_err(out['V_updated'].cpu(), Vu) < 2e-5
+    Nt = R.computer_face_normal(torch.from_numpy(clean), fv64)
+    assert abs(out['angle1'] - R.error_n(no, Nt).item()) < 1e-3
+    assert abs(out['angle2'] - R.error_n(R.computer_face_normal(Vu, fv64), Nt).item()) < 1e-3
+
+
+_MP_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from geobi_gnn_amd import network, patches, meshgen
+from geobi_gnn_amd.parallel import init_distributed
+rank, world, device = init_distributed()
+assert world == 2 and device.type == 'cuda'
+torch.manual_seed(0)
+net = network.DualGNN().to(device).eval()
+noisy, clean, faces = meshgen.noisy_icosphere(20, 0.2, seed=31)            # F = 8000 -> 5 patches of 2000 faces
+out = patches.predict_mesh(net, noisy, faces, sub_size=2000, n_iter=10, gt_points=clean)
+assert out['n_patches'] >= 4
+if rank == 0:
+    solo = patches.predict_mesh(net, noisy, faces, sub_size=2000, n_iter=10, gt_points=clean, distributed=False)
+    assert solo['n_patches'] == out['n_patches']
+    # each patch's prediction is the same bits on either rank; only the order of the merge additions differs
+    assert float((solo['Vp'] - out['Vp']).abs().max()) <= 1e-5 * float(solo['Vp'].abs().max())
+    assert float((solo['Np'] - out['Np']).abs().max()) <= 1e-5
+    assert abs(solo['angle1'] - out['angle1']) < 1e-3 and abs(solo['angle2'] - out['angle2']) < 1e-3
+else:
+    assert out['Vp'] is None and out['V_updated'] is None
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_patch_scatter_two_ranks_on_one_device(dev, tmp_path):
+    """SURVEY 8e inference sharding, rehearsed with 2 ranks sharing this box's one GPU (gloo): the ranks take
+    alternate patches of one mesh, one reduction merges them on rank 0, result == the single-rank run."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'mp_worker.py'
+    script.write_text(_MP_WORKER % {'root': root})
+    env = dict(os.environ, GEOBI_ALL_RANKS_ON_DEVICE0='1', GEOBI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29751', str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count('ok') == 2

@@ -181,6 +181,63 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert out.stdout.count('ok') == 2
 
 
+_PATCH_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from geobi_gnn_amd.parallel import init_distributed, owns_patch, reduce_patch_sums, rank_world
+rank, world, device = init_distributed('gloo')
+assert (rank, world) == rank_world() and world == 2 and device.type == 'cpu'
+fx = np.load(os.path.join(%(root)r, 'tests', 'golden', 'patches_n8.npz'))
+V, F = fx['points'].shape[0], fx['faces'].shape[0]
+
+def accumulate(keep):
+    """test_dual.py:53-58 over the fixture's patches with a stand-in prediction per patch (the network itself
+    only runs on the MI355X); what geobi_patch_accumulate does, in torch."""
+    Vp, Np, cnt = torch.zeros(V, 3), torch.zeros(F, 3), torch.zeros(V, dtype=torch.int32)
+    fo = vo = 0
+    for k, (nf, nv) in enumerate(fx['sizes']):
+        sel = torch.from_numpy(fx['select_faces'][fo:fo + nf]).long()
+        v_idx = torch.from_numpy(fx['v_idx'][vo:vo + nv]).long()
+        fo += nf; vo += nv
+        if not keep(k):
+            continue
+        g = torch.Generator().manual_seed(k)
+        Vp[v_idx] += torch.randn(nv, 3, generator=g)
+        Np[sel] += torch.randn(nf, 3, generator=g)
+        cnt[v_idx] += 1
+    return Vp, Np, cnt
+
+mine = accumulate(lambda k: owns_patch(k, rank, world))
+owned = [k for k in range(len(fx['sizes'])) if owns_patch(k, rank, world)]
+both = [None, None]
+dist.all_gather_object(both, owned)
+assert sorted(both[0] + both[1]) == list(range(len(fx['sizes']))) and not set(both[0]) & set(both[1])
+reduce_patch_sums(list(mine), dst=0)
+if rank == 0:
+    full = accumulate(lambda k: True)
+    assert torch.equal(mine[2], full[2]) and int(full[2].min()) >= 1
+    assert torch.allclose(mine[0], full[0], atol=1e-6) and torch.allclose(mine[1], full[1], atol=1e-6)
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_patch_scatter_gloo_world2(tmp_path):
+    """Multi-GPU inference (SURVEY 8e): the patches of one mesh dealt over 2 ranks and reduced onto rank 0 give the
+    single-rank sums (partition is exact and disjoint; visit counts bit-equal)."""
+    script = tmp_path / 'patch_worker.py'
+    script.write_text(_PATCH_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29741', OMP_NUM_THREADS='2',
+               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29741', str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count('ok') == 2
+
+
 def test_op_tape_matches_autograd_on_a_dag():
     """ops.Tape (the reverse-mode tape DualGNN runs its ~70 ops through) against torch.autograd on a
     small DAG with a tensor used twice, a two-output-gradient op and a branch without gradient."""
