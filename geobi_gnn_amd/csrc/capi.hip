@@ -156,7 +156,7 @@ int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
                     float* wf, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c); NOTNULL(bias);
-  NOTNULL(out); NOTNULL(p); NOTNULL(z);
+  NOTNULL(out); NOTNULL(p);
   if (Cb > 0) NOTNULL(xb);
   if (E > 0) NOTNULL(col_in);
   GEOBI_TRY(check_channels(__func__, Ca + Cb, Cout));
@@ -173,7 +173,7 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(rowptr_out); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c);
-  NOTNULL(gout); NOTNULL(p); NOTNULL(z); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
+  NOTNULL(gout); NOTNULL(p); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
   if (slope != 1.0f) NOTNULL(out);
   if (Cb > 0) { NOTNULL(xb); if (dxa) NOTNULL(dxb); }
   if (E > 0) { NOTNULL(col_in); NOTNULL(col_out); NOTNULL(pos_in); }

@@ -89,8 +89,26 @@ static inline size_t gemm_nn_ws_bytes(int64_t M, int N) {
 // forward GEMM of a FeaSt layer: the split is a function of the layer shape only
 // packed-weight buffer shared by forward and backward: Wf [ldz(Cin), Cout] for z Wf / g Wf^T, then
 // W' [ldr(Cout), Cin] = [lin.weight ; u.weight ; 0] for dx = r' W'
-static inline size_t feast_wpack_floats(int Cin, int Cout) {
+// feast_fused.hip: the fused (aggregate -> LDS tile -> MFMA) kernels and their packed weights
+int feast_fused_nt(int nout);
+size_t feast_fused_fwd_pack_floats(int Cin, int Cout);
+size_t feast_fused_dx_pack_floats(int Cin, int Cout);
+int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s);
+int feast_fused_pack_dx(const float* lin_w, const float* u_w, int Cin, int Cout, float* bp, hipStream_t s);
+double feast_fused_bytes(int64_t N, int64_t E, int C, int nout);
+int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
+                    const int* rowptr, const int* col, int N, int LC, const float* ul, const float* Bp, int Cout,
+                    const float* bias, float slope, float* out, hipStream_t s);
+int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, const int* rowptr_out,
+                   const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
+                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, hipStream_t s);
+// packed-weight buffer layout: [Wf | W' | Bf (fused forward) | Bdx (fused dx)]
+static inline size_t feast_wpack_plain_floats(int Cin, int Cout) {
   return (size_t)((GEOBI_H * Cin + 3) / 4 * 4) * Cout + (size_t)(GEOBI_H * Cout + 2 * GEOBI_HP) * Cin;
+}
+static inline size_t feast_wpack_floats(int Cin, int Cout) {
+  return feast_wpack_plain_floats(Cin, Cout) + feast_fused_fwd_pack_floats(Cin, Cout) +
+         feast_fused_dx_pack_floats(Cin, Cout);
 }
 static inline int feast_fwd_slices(int Kp, int Cout) { return Kp >= 1024 ? 4 : ((Kp >= 512 && Cout >= 64) ? 2 : 1); }
 static inline size_t gemm_nn_fixed_ws_bytes(int64_t M, int N, int slices) {

@@ -14,118 +14,13 @@
 //   column pass over sources j: r_j[h,:] = sum_i q_ijh/deg_i g_i  (same gather kernel, transposed CSR);
 //   dx = [r | dp] [lin.weight ; u.weight];  dW = z^T g;  du = dp^T x;  dc, dbias column sums.
 #include "common.h"
+#include "feast_dev.h"
 
 namespace geobi {
 
 namespace {
 
-constexpr int H = GEOBI_H;
-constexpr int HP = GEOBI_HP;
-
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS ops of one wave execute in order; this only stops the compiler moving them across.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ void softmax9(float (&l)[H]) {
-  float m = l[0];
-#pragma unroll
-  for (int h = 1; h < H; ++h) m = fmaxf(m, l[h]);
-  float s = 0.f;
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    l[h] = expf(l[h] - m);
-    s += l[h];
-  }
-  float inv = 1.0f / s;
-#pragma unroll
-  for (int h = 0; h < H; ++h) l[h] *= inv;
-}
-
-__device__ __forceinline__ void load_hp(const float* __restrict__ row, float (&v)[H]) {
-  const float4* r4 = reinterpret_cast<const float4*>(row);
-  float4 a = r4[0], b = r4[1], c = r4[2];
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  v[8] = c.x;
-}
-
-// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its
-// own L2.  A node's neighbours are mostly nearby nodes, so a contiguous eighth of the node range per XCD
-// keeps every gathered row in ONE L2 instead of eight: launched block b works on virtual block
-// (b % 8) * (grid / 8) + b / 8.  The grid is padded to a multiple of 8; the surplus blocks land beyond N and exit.
-__host__ __device__ __forceinline__ int xcd_grid(int blocks) { return (blocks + 7) / 8 * 8; }
-__device__ __forceinline__ int xcd_block(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* __restrict__ ptr, float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    float4 t = *reinterpret_cast<const float4*>(ptr);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = ptr[i];
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* __restrict__ ptr, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) ptr[i] = v[i];
-  }
-}
-
-// Per-edge logits of the layers that read raw mesh coordinates (Cin = 6 / 12, level 0): there the features are
-// positions scaled by 1 / mean edge length, |x| ~ 27 at n = 32 and ~ 72 at n = 87, and the node-level form
-// p_j - p_i (p = x u^T) loses |x| / |x_j - x_i| in the subtraction.  These layers therefore evaluate
-// u (x_j - x_i) per edge exactly as the reference does: the difference of two nearby coordinates is (nearly)
-// exact in fp32, and a level-0 row is only 24 / 48 B -- no more than the 48-B logit row it replaces.
-// LDS image of u: [LC][HP] (head-minor, 3 x float4 per input channel).
-template <int LC>
-__device__ __forceinline__ void stage_u(const float* __restrict__ u, float* s_u) {
-  for (int i = threadIdx.x; i < LC * HP; i += blockDim.x) {
-    const int k = i / HP, h = i % HP;
-    s_u[i] = h < H ? u[h * LC + k] : 0.f;
-  }
-  __syncthreads();
-}
-
-template <int LC>
-__device__ __forceinline__ void load_row(const float* __restrict__ row, float (&v)[LC]) {
-  if constexpr ((LC & 3) == 0) {
-#pragma unroll
-    for (int i = 0; i < LC; i += 4) {
-      float4 t = *reinterpret_cast<const float4*>(row + i);
-      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < LC; i += 2) {
-      float2 t = *reinterpret_cast<const float2*>(row + i);
-      v[i] = t.x; v[i + 1] = t.y;
-    }
-  }
-}
-
-// l_h = c_h + sum_k u[h,k] d[k]
-template <int LC>
-__device__ __forceinline__ void edge_logits(const float (&d)[LC], const float* s_u, const float (&cc)[H], float (&l)[H]) {
-#pragma unroll
-  for (int h = 0; h < H; ++h) l[h] = cc[h];
-#pragma unroll
-  for (int k = 0; k < LC; ++k) {
-    const float4* r = reinterpret_cast<const float4*>(s_u + k * HP);
-    const float4 a = r[0], b = r[1], c = r[2];
-    l[0] = fmaf(a.x, d[k], l[0]); l[1] = fmaf(a.y, d[k], l[1]); l[2] = fmaf(a.z, d[k], l[2]);
-    l[3] = fmaf(a.w, d[k], l[3]); l[4] = fmaf(b.x, d[k], l[4]); l[5] = fmaf(b.y, d[k], l[5]);
-    l[6] = fmaf(b.z, d[k], l[6]); l[7] = fmaf(b.w, d[k], l[7]); l[8] = fmaf(c.x, d[k], l[8]);
-  }
-}
+using namespace feast_dev;
 
 // ----------------------------------------------------------------------------- logits
 template <int C>
@@ -688,7 +583,8 @@ double feast_agg_bytes(int64_t N, int64_t E, int C, int ld_out) {
 
 size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) {
   const int Kp = feast_ldz(Cin);
-  return align_up((size_t)Kp * Cout * sizeof(float)) + gemm_nn_fixed_ws_bytes(N, Cout, feast_fwd_slices(Kp, Cout)) + 512;
+  return align_up((size_t)Kp * Cout * sizeof(float)) + align_up(feast_fused_fwd_pack_floats(Cin, Cout) * sizeof(float)) +
+         gemm_nn_fixed_ws_bytes(N, Cout, feast_fwd_slices(Kp, Cout)) + 1024;
 }
 
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
@@ -700,6 +596,27 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_REQUIRE(Cb == 0 || Ca == Cb, "feast_fwd: a split input must have two equal halves");
   const int Kp = feast_ldz(Cin);
   Arena a(ws, ws_bytes);
+  if (z == nullptr) {
+    // Fused path: aggregation + node transform in one kernel, z never reaches HBM (feast_fused.hip).
+    const size_t plain = feast_wpack_plain_floats(Cin, Cout);
+    float* bf = wf_out ? wf_out + plain : a.take<float>(feast_fused_fwd_pack_floats(Cin, Cout));
+    GEOBI_REQUIRE(a.ok() && bf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, bf, s));
+    if (wf_out != nullptr) {      // the backward's packed forms: Wf, W' and the fused dx weights
+      const int ldr_ = feast_ldr(Cout);
+      pack_weights_kernel<<<cdiv((int64_t)Kp * Cout + (int64_t)ldr_ * Cin, 256), 256, 0, s>>>(
+          lin_w, u_w, Cin, Cout, Kp, ldr_, wf_out, wf_out + (size_t)Kp * Cout);
+      GEOBI_LAUNCH_OK();
+      GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, Cin, Cout, bf + feast_fused_fwd_pack_floats(Cin, Cout), s));
+    }
+    const int LCf = edge_logit_channels(Cin, Cb);
+    if (LCf == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
+    prof_begin(PROF_AGG_FWD, s, feast_fused_bytes(N, Ecap, Cin, Cout), Cin);
+    int rcf = feast_fused_fwd(xa, xb ? xb : xa, Cb ? Ca : Cin, Cin, p, cvec, rowptr_in, col_in, (int)N, LCf, u_w, bf,
+                              Cout, bias, slope, out, s);
+    prof_end(PROF_AGG_FWD, s);
+    return rcf;
+  }
   float* wf = wf_out ? wf_out : a.take<float>((size_t)Kp * Cout);   // packed weights, kept for the backward
   const int fwd_slices = feast_fwd_slices(Kp, Cout);
   const size_t gws = gemm_nn_fixed_ws_bytes(N, Cout, fwd_slices);
@@ -732,7 +649,7 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
 
 struct BwdPlan {
   size_t total;
-  float *g, *wf, *dz, *dl, *dpn, *rp, *wp;
+  float *g, *wf, *dz, *dl, *dpn, *rp, *wp, *z, *bdx;
   void *tn_ws, *tn_ws2, *gemm_ws;
   size_t tn_bytes, tn_bytes2, gemm_bytes;
 };
@@ -746,6 +663,8 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.dpn = a.take<float>((size_t)N * HP);
   b.rp = a.take<float>((size_t)N * ldr);
   b.wp = a.take<float>((size_t)ldr * Cin);
+  b.z = a.take<float>((size_t)N * Kp);                       // fused forward: z is recomputed here
+  b.bdx = a.take<float>(feast_fused_dx_pack_floats(Cin, Cout));
   b.tn_bytes = gemm_tn_ws_bytes(Kp + 1, Cout, N);           // [z | 1]^T g   (side stream)
   b.tn_ws = a.take<char>(b.tn_bytes);
   b.tn_bytes2 = gemm_tn_ws_bytes_any_width(2 * HP, Cin + 1, N);   // [dp | dcs]^T [x | 1], per input half
@@ -791,6 +710,13 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     GEOBI_LAUNCH_OK();
     g = b.g;
   }
+  const int LC = edge_logit_channels(Cin, Cb);
+  // Fused forward (z == NULL): the aggregated rows were never written; recompute them for dW = z^T g
+  const bool fused = z == nullptr;
+  if (fused) {
+    GEOBI_TRY(launch_aggregate<0>(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, nullptr, (int)N, b.z, Kp, LC, xa, u_w, s));
+    z = b.z;
+  }
   // 2'. weight + bias gradient [z | 1]^T g: needs only z and g, nothing downstream needs it -> side stream
   Fork fk = fork_side_stream(s);
   {
@@ -811,14 +737,15 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_TRY(gemm_nn(g, Cout, wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
-  const int LC = edge_logit_channels(Cin, Cb);
+  // [dp | dcs]: the tail columns of r' (unfused dx GEMM) or a compact [N, 24] array (fused dx kernel)
+  float* dpd = fused ? b.rp : b.rp + H * Cout;
+  const int ld_dpd = fused ? 2 * HP : ldr;
   int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,
-                          b.rp + H * Cout + HP, ldr, LC, u_w, s);
+                          dpd + HP, ld_dpd, LC, u_w, s);
   prof_end(PROF_ROWPASS, s);
   GEOBI_TRY(rc);
   // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
-  feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, b.rp, ldr,
-                                                          H * Cout);
+  feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, dpd, ld_dpd, 0);
   GEOBI_LAUNCH_OK();
   // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]; needs the row
   //    pass and dp_gather only -> also off the critical path (side stream, after an event on main)
@@ -830,9 +757,9 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     float* partial = (float*)b.tn_ws2;
     GEOBI_REQUIRE((size_t)blocks * (H * LC + H) * sizeof(float) <= b.tn_bytes2, "feast_bwd: du workspace too small");
     if (LC == 6)
-      feast_du_edge_kernel<6><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, b.rp + H * Cout + HP, ldr, (int)N, partial);
+      feast_du_edge_kernel<6><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, dpd + HP, ld_dpd, (int)N, partial);
     else
-      feast_du_edge_kernel<12><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, b.rp + H * Cout + HP, ldr, (int)N, partial);
+      feast_du_edge_kernel<12><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, dpd + HP, ld_dpd, (int)N, partial);
     GEOBI_LAUNCH_OK();
     feast_du_final_kernel<<<1, 128, 0, ss>>>(partial, blocks, LC, accumulate, du_w, dc);
     GEOBI_LAUNCH_OK();
@@ -841,13 +768,26 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     hipStream_t ss = fk.side ? fk.side : s;
     TnOutput ou;
     ou.mode = TN_DU_DC; ou.C = du_w; ou.ldc = Cin; ou.C2 = dc; ou.accumulate = accumulate;
-    GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws2, b.tn_bytes2, ss));
+    GEOBI_TRY(gemm_tn(dpd, ld_dpd, xa, Ca_, N, 2 * HP, Ca_ + 1, -1, Ca_, ou, b.tn_ws2, b.tn_bytes2, ss));
     if (Cb) {
       ou.C = du_w + Ca; ou.C2 = nullptr;
-      GEOBI_TRY(gemm_tn(b.rp + H * Cout, ldr, xb, Cb, N, 2 * HP, Cb + 1, -1, Cb, ou, b.tn_ws2, b.tn_bytes2, ss));
+      GEOBI_TRY(gemm_tn(dpd, ld_dpd, xb, Cb, N, 2 * HP, Cb + 1, -1, Cb, ou, b.tn_ws2, b.tn_bytes2, ss));
     }
   }
-  if (dxa != nullptr) {
+  if (dxa != nullptr && fused) {
+    // dx = [r | dp | dcs] W' in one kernel: the transposed aggregation feeds the MFMA tile through LDS
+    const float* bdx = b.bdx;
+    if (wf_saved != nullptr) {
+      bdx = wf_saved + feast_wpack_plain_floats(Cin, Cout) + feast_fused_fwd_pack_floats(Cin, Cout);
+    } else {
+      GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, Cin, Cout, b.bdx, s));
+    }
+    prof_begin(PROF_AGG_BWD, s, feast_fused_bytes(N, Ecap, Cout, Cin), Cout);
+    rc = feast_fused_dx(g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, LC, xa, u_w, dpd, bdx, Cin, dxa,
+                        Cb ? Ca : Cin, dxb, Cb, s);
+    prof_end(PROF_AGG_BWD, s);
+    GEOBI_TRY(rc);
+  } else if (dxa != nullptr) {
     prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);
     rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, LC, xa, u_w,
                              s);

@@ -1,0 +1,118 @@
+// Device helpers shared by the FeaSt kernels (feast.hip, feast_fused.hip).  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace geobi {
+namespace feast_dev {
+
+constexpr int H = GEOBI_H;
+constexpr int HP = GEOBI_HP;
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS ops of one wave execute in order; this only stops the compiler moving them across.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void softmax9(float (&l)[H]) {
+  float m = l[0];
+#pragma unroll
+  for (int h = 1; h < H; ++h) m = fmaxf(m, l[h]);
+  float s = 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    l[h] = expf(l[h] - m);
+    s += l[h];
+  }
+  float inv = 1.0f / s;
+#pragma unroll
+  for (int h = 0; h < H; ++h) l[h] *= inv;
+}
+
+__device__ __forceinline__ void load_hp(const float* __restrict__ row, float (&v)[H]) {
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+  float4 a = r4[0], b = r4[1], c = r4[2];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x;
+}
+
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its
+// own L2.  A node's neighbours are mostly nearby nodes, so a contiguous eighth of the node range per XCD
+// keeps every gathered row in ONE L2 instead of eight: launched block b works on virtual block
+// (b % 8) * (grid / 8) + b / 8.  The grid is padded to a multiple of 8; the surplus blocks land beyond N and exit.
+__host__ __device__ __forceinline__ int xcd_grid(int blocks) { return (blocks + 7) / 8 * 8; }
+__device__ __forceinline__ int xcd_block(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ ptr, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(ptr);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = ptr[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ ptr, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ptr[i] = v[i];
+  }
+}
+
+// Per-edge logits of the layers that read raw mesh coordinates (Cin = 6 / 12, level 0): there the features are
+// positions scaled by 1 / mean edge length, |x| ~ 27 at n = 32 and ~ 72 at n = 87, and the node-level form
+// p_j - p_i (p = x u^T) loses |x| / |x_j - x_i| in the subtraction.  These layers therefore evaluate
+// u (x_j - x_i) per edge exactly as the reference does: the difference of two nearby coordinates is (nearly)
+// exact in fp32, and a level-0 row is only 24 / 48 B -- no more than the 48-B logit row it replaces.
+// LDS image of u: [LC][HP] (head-minor, 3 x float4 per input channel).
+template <int LC>
+__device__ __forceinline__ void stage_u(const float* __restrict__ u, float* s_u) {
+  for (int i = threadIdx.x; i < LC * HP; i += blockDim.x) {
+    const int k = i / HP, h = i % HP;
+    s_u[i] = h < H ? u[h * LC + k] : 0.f;
+  }
+  __syncthreads();
+}
+
+template <int LC>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, float (&v)[LC]) {
+  if constexpr ((LC & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < LC; i += 4) {
+      float4 t = *reinterpret_cast<const float4*>(row + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < LC; i += 2) {
+      float2 t = *reinterpret_cast<const float2*>(row + i);
+      v[i] = t.x; v[i + 1] = t.y;
+    }
+  }
+}
+
+// l_h = c_h + sum_k u[h,k] d[k]
+template <int LC>
+__device__ __forceinline__ void edge_logits(const float (&d)[LC], const float* s_u, const float (&cc)[H], float (&l)[H]) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) l[h] = cc[h];
+#pragma unroll
+  for (int k = 0; k < LC; ++k) {
+    const float4* r = reinterpret_cast<const float4*>(s_u + k * HP);
+    const float4 a = r[0], b = r[1], c = r[2];
+    l[0] = fmaf(a.x, d[k], l[0]); l[1] = fmaf(a.y, d[k], l[1]); l[2] = fmaf(a.z, d[k], l[2]);
+    l[3] = fmaf(a.w, d[k], l[3]); l[4] = fmaf(b.x, d[k], l[4]); l[5] = fmaf(b.y, d[k], l[5]);
+    l[6] = fmaf(b.z, d[k], l[6]); l[7] = fmaf(b.w, d[k], l[7]); l[8] = fmaf(c.x, d[k], l[8]);
+  }
+}
+
+
+}  // namespace feast_dev
+}  // namespace geobi

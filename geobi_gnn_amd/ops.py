@@ -4,6 +4,8 @@ Each Function replaces one third-party op of the reference's hot path; the repla
 site is cited in the docstring.  Tensors are allocated by PyTorch's caching allocator and
 handed to the library as borrowed device pointers on torch's current HIP stream.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -11,6 +13,9 @@ from . import _lib as L
 
 LEAK = 0.2
 HP = 12   # GEOBI_HEAD_STRIDE
+# GEOBI_FUSED=0: separate aggregation + GEMM kernels with the aggregated rows z [N, 9 Cin] written to HBM
+# (the round-1 path, kept for A/B timing and as the second implementation the fused kernels are tested against)
+FUSED = os.environ.get('GEOBI_FUSED', '1') == '1'
 
 
 # ----------------------------------------------------------------------------- op tape
@@ -174,7 +179,7 @@ class FeastConvFn(Function):
         ldz = L.size_query('geobi_feast_ldz', Cin)
         out = torch.empty((N, Cout), dtype=torch.float32, device=dev)
         p = torch.empty((N, HP), dtype=torch.float32, device=dev)
-        z = torch.empty((N, ldz), dtype=torch.float32, device=dev)
+        z = None if FUSED else torch.empty((N, ldz), dtype=torch.float32, device=dev)
         # packed weights (Wf | W'), reused by the backward; not kept when nothing needs a gradient
         wf = None
         if any(ctx.needs_input_grad):
@@ -183,8 +188,9 @@ class FeastConvFn(Function):
         L.call('geobi_feast_fwd', L.ptr(xa), L.ptr(xb), Ca, Cb, N, g.E, L.ptr(g.rowptr_in), L.ptr(g.col_in),
                L.ptr(lin_w), L.ptr(u_w), L.ptr(c), L.ptr(bias), Cout, float(slope), L.ptr(out), L.ptr(p), L.ptr(z),
                L.ptr(wf), L.ptr(ws), ws.numel(), L.stream())
-        ctx.graph, ctx.slope, ctx.has_b, ctx.has_wf = g, float(slope), xb is not None, wf is not None
-        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z, wf if wf is not None else p)
+        ctx.graph, ctx.slope, ctx.has_b, ctx.has_wf, ctx.has_z = g, float(slope), xb is not None, wf is not None, z is not None
+        ctx.save_for_backward(xa, xb if xb is not None else xa, lin_w, u_w, c, out, p, z if z is not None else p,
+                              wf if wf is not None else p)
         return out
 
     @staticmethod
@@ -192,6 +198,8 @@ class FeastConvFn(Function):
         xa, xb, lin_w, u_w, c, out, p, z, wf = ctx.saved_tensors
         if not ctx.has_wf:
             wf = None
+        if not ctx.has_z:
+            z = None
         g = ctx.graph
         if not ctx.has_b:
             xb = None

@@ -73,11 +73,17 @@ int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst
  *   out-CSR : rowptr_out/col_out -- for every SOURCE node its TARGET nodes; pos_in[e] = position of
  *             out-edge e in the in-CSR.  Both without self loops (one per node is implied).
  *   lin_w [9*Cout, Cin], u_w [9, Cin], c [9], bias [Cout]   (PyG >= 2.0 state-dict layout)
- *   forward saves p [N, 12] (x u^T) and z [N, geobi_feast_ldz(Cin)] (aggregated features) for the
- *   backward; `out` after the activation is needed by the backward when slope != 1.  wf (optional,
- *   geobi_feast_wpack_floats(Cin, Cout) floats) receives the packed weights -- Wf [ldz, Cout] followed by
- *   W' = [lin.weight ; u.weight ; 0] [9 Cout + 24, Cin] -- in the forward and, handed back to the backward,
- *   saves repacking them there (NULL: packed into the workspace on both sides).
+ *   forward saves p [N, 12] (x u^T; not written for unsplit 6- / 12-channel inputs, whose logits are formed
+ *   per edge from the rows themselves) for the backward; `out` after the activation is needed by the backward
+ *   when slope != 1.
+ *   z == NULL (the default of the Python layer): FUSED path -- aggregation and node transform in one kernel, the
+ *   aggregated features [N, 9 Cin] stay in LDS and never reach HBM; the backward (z == NULL as well) recomputes
+ *   them and forms dx in a second fused kernel.  z != NULL: [N, geobi_feast_ldz(Cin)] receives the aggregated
+ *   features (separate aggregation + GEMM kernels) and must be handed to the backward.
+ *   wf (optional, geobi_feast_wpack_floats(Cin, Cout) floats) receives the packed weights -- Wf [ldz, Cout],
+ *   W' = [lin.weight ; u.weight ; 0] [9 Cout + 24, Cin], then the MFMA-fragment-ordered forms of both that the
+ *   fused kernels read -- in the forward and, handed back to the backward, saves repacking them there (NULL:
+ *   packed into the workspace on both sides).
  *   E = number of edges in the CSR (used for scratch sizing and byte accounting only).
  *   Supported channel counts: Cin, Cout in {6, 12, 32, 64, 128} (Cout: 32, 64, 128).           */
 int geobi_feast_ldz(int Cin);

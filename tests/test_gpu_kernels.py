@@ -103,7 +103,21 @@ def test_gemm_tn(dev, M, I, J):
 
 
 # ------------------------------------------------------------------------- FeaSt conv
-def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0, x=None):
+def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0, x=None, fused=True):
+    """fused=True: the default path (aggregation + node transform in one kernel, feast_fused.hip);
+    fused=False: separate aggregation and GEMM kernels with z in HBM (GEOBI_FUSED=0)."""
+    from geobi_gnn_amd import ops
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    from oracle import pyg_ops as P
+    was = ops.FUSED
+    ops.FUSED = bool(fused)
+    try:
+        return _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x)
+    finally:
+        ops.FUSED = was
+
+
+def _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x):
     from geobi_gnn_amd.feast_conv import FeaStConv
     from oracle import pyg_ops as P
     torch.manual_seed(seed)
@@ -137,14 +151,16 @@ def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0, x=None):
     return errs
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('Cin,Cout,slope,split', [(6, 32, 0.2, False), (12, 32, 0.2, False), (32, 64, 0.2, False),
                                                   (64, 128, 0.2, False), (128, 128, 0.2, False),
                                                   (128, 64, 1.0, False), (128, 64, 0.2, True),
-                                                  (64, 32, 1.0, False), (64, 32, 0.2, True)])
-def test_feast_conv_random_graph(dev, Cin, Cout, slope, split):
-    n = 700
+                                                  (64, 32, 1.0, False), (64, 32, 0.2, True),
+                                                  (6, 64, 0.2, True), (12, 128, 1.0, False), (32, 32, 0.2, False)])
+def test_feast_conv_random_graph(dev, Cin, Cout, slope, split, fused):
+    n = 700          # 21 full tiles of 32 nodes + a ragged one
     ei = _sym_graph(n, 2500, seed=Cin + Cout)
-    errs = _run_feast(dev, Cin, Cout, ei, n, slope, split, seed=Cin * 7 + Cout)
+    errs = _run_feast(dev, Cin, Cout, ei, n, slope, split, seed=Cin * 7 + Cout, fused=fused)
     assert max(errs.values()) < TOL, errs
 
 
@@ -155,8 +171,9 @@ def test_feast_conv_directed_graph_and_isolated_nodes(dev):
     ei = torch.randint(0, n - 20, (2, 4000), generator=g)          # last 20 nodes isolated
     hub = torch.stack([torch.arange(1, 201), torch.zeros(200, dtype=torch.long)])   # node 0: in-degree 200+
     ei = torch.cat([ei, hub], 1)
-    errs = _run_feast(dev, 32, 64, ei, n, 0.2, False, seed=11)
-    assert max(errs.values()) < TOL, errs
+    for fused in (True, False):
+        errs = _run_feast(dev, 32, 64, ei, n, 0.2, False, seed=11, fused=fused)
+        assert max(errs.values()) < TOL, (fused, errs)
 
 
 def test_feast_conv_large_logits(dev):

@@ -220,6 +220,6 @@ def test_patch_scatter_two_ranks_on_one_device(dev, tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', '29751', str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
