@@ -13,9 +13,10 @@ Timed region: forward, loss, backward, gradient all-reduce, optimiser step.  Inp
 in HBM before the clock starts.
 
 metric  M-edges/s = level-0 edge_index columns of all meshes of all ranks / wall seconds.
-roofline  the forward FeaSt aggregation kernel ("scatter-add" of the path), its dominant
-          instantiation: ALGORITHMIC bytes (B_agg with z written out) / launch
-          time measured with HIP events on the launch stream in a separate pass.
+roofline  the forward fused FeaSt kernel (aggregation -- the "scatter-add" of the path -- with the node
+          transform fused behind it), its dominant instantiation: ALGORITHMIC bytes (SURVEY.md 8d,
+          B_agg with the fused write term 4 N C_out) / launch time measured with HIP events on the
+          launch stream in a separate pass; `traffic` / `frac_by_counters` quote the committed PMC passes.
 cpu_baseline  the PyG-shaped CPU oracle (same op decomposition as the reference) on ONE mesh of
           the same size, all host cores, rank 0 at N = 1 only.
 """
@@ -66,7 +67,9 @@ def train_step(net, bucket, opt, dv0, df0, collective=True):
 
 
 def measure_roofline(net, bucket, opt, dv, df, steps=3):
-    """Separate pass: every forward-aggregation launch bracketed by HIP events on its stream."""
+    """Separate pass: every forward launch of the fused FeaSt kernel (aggregation = the path's "scatter-add", with the
+    node transform fused behind it through LDS) bracketed by HIP events on its stream.  ALGORITHMIC bytes per launch =
+    SURVEY.md 8d's B_agg with the fused write term W = 4 N C_out (csrc/feast_fused.hip: feast_fused_bytes)."""
     from geobi_gnn_amd import _lib as L
     lib = L.lib()
     lib.geobi_prof_enable(1)
@@ -75,28 +78,37 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
     torch.cuda.synchronize()
     best = None
     total = {'launches': 0, 'ms': 0.0, 'bytes': 0.0}
-    for tag in (6, 12, 32, 64, 128):
-        n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
-        L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), 'prof_collect')
-        if n.value == 0:
-            continue
-        total['launches'] += n.value; total['ms'] += ms.value; total['bytes'] += by.value
-        if best is None or ms.value > best['ms']:
-            best = {'tag': tag, 'launches': n.value, 'ms': ms.value, 'bytes': by.value}
+    for cin in (6, 12, 32, 64, 128):
+        for cout in (32, 64, 128):
+            n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+            L.check(lib.geobi_prof_collect(cin * 1000 + cout, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)),
+                    'prof_collect')
+            if n.value == 0:
+                continue
+            total['launches'] += n.value; total['ms'] += ms.value; total['bytes'] += by.value
+            if best is None or ms.value > best['ms']:
+                best = {'cin': cin, 'cout': cout, 'launches': n.value, 'ms': ms.value, 'bytes': by.value}
     lib.geobi_prof_enable(0)
     ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
-    kname = 'feast_aggregate_kernel<%d,%d,0>' % (best['tag'], 3 if best['tag'] in (6, 12) else 4)
+    lc = best['cin'] if best['cin'] in (6, 12) else 0
+    kname = 'feast_fused_kernel<%d,%d,0,%d,%d>' % (best['cin'], 3 if best['cin'] in (6, 12) else 4, lc, best['cout'] // 32)
+    avg_us = best['ms'] * 1e3 / best['launches']
     traffic, traffic_src = pmc_traffic(kname)
-    return {
+    out = {
         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-        'kernel': kname,
-        'launches': best['launches'], 'avg_us': round(best['ms'] * 1e3 / best['launches'], 2),
+        'frac': round(ach / HBM_PEAK_GBS, 4),
+        # HBM bytes per launch by the PMC counters: QUOTED from the committed rocprofv3 --pmc passes over this same
+        # workload (counters cannot be read from inside the process), not measured in this run
+        'traffic': traffic, 'traffic_source': traffic_src,
+        'frac_by_counters': None if traffic is None else round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        'kernel': kname, 'layer': 'FeaStConv %d -> %d' % (best['cin'], best['cout']),
+        'launches': best['launches'], 'avg_us': round(avg_us, 2),
         'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
         'all_instantiations': {'launches': total['launches'],
                                'achieved': round(total['bytes'] / (total['ms'] * 1e-3) / 1e9, 1),
                                'avg_us': round(total['ms'] * 1e3 / total['launches'], 2)},
     }
+    return out
 
 
 def measure_mfma(net, bucket, opt, dv, df, steps=3):
@@ -152,14 +164,17 @@ def log(msg):
     print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
+PMC_SUMMARY = 'profiles/r02_pmc_feast_fused.json'
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch from the PMC counters.  They cannot be collected from inside this
     process (rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE separately); the committed summary of
     those passes over this same workload is quoted, or null when it is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_feast_aggregate.json')
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
         k = json.load(open(path))['kernels'][kernel]
-        return k['hbm_bytes_per_launch'], 'profiles/r01_pmc_feast_aggregate.json (tools/pmc_summary.py)'
+        return k['hbm_bytes_per_launch'], 'quoted from %s (tools/pmc_summary.py)' % PMC_SUMMARY
     except (OSError, KeyError, ValueError):
         return None, None
 

@@ -95,13 +95,16 @@ size_t feast_fused_fwd_pack_floats(int Cin, int Cout);
 size_t feast_fused_dx_pack_floats(int Cin, int Cout);
 int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s);
 int feast_fused_pack_dx(const float* lin_w, const float* u_w, int Cin, int Cout, float* bp, hipStream_t s);
+int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout, int Kp, float* wf, float* bf,
+                         float* bdx, hipStream_t s);
 double feast_fused_bytes(int64_t N, int64_t E, int C, int nout);
 int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
                     const int* rowptr, const int* col, int N, int LC, const float* ul, const float* Bp, int Cout,
                     const float* bias, float slope, float* out, hipStream_t s);
 int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, const int* rowptr_out,
                    const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
-                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, hipStream_t s);
+                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
+                   hipStream_t s);
 // packed-weight buffer layout: [Wf | W' | Bf (fused forward) | Bdx (fused dx)]
 static inline size_t feast_wpack_plain_floats(int Cin, int Cout) {
   return (size_t)((GEOBI_H * Cin + 3) / 4 * 4) * Cout + (size_t)(GEOBI_H * Cout + 2 * GEOBI_HP) * Cin;
@@ -119,7 +122,7 @@ int gemm_nn(const float* A, int lda, const float* B, int ldb, int transB, float*
             const GemmEpilogue& ep, hipStream_t s);
 size_t gemm_tn_ws_bytes(int I, int J, int64_t M);
 size_t gemm_tn_ws_bytes_any_width(int I, int J, int64_t M);   // max over column widths 1..J
-enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1, TN_DU_DC = 2 };
+enum TnOut { TN_PLAIN = 0, TN_LIN_UNPACK = 1, TN_DU_DC = 2, TN_RPRIME = 3 };
 struct TnOutput {
   int mode = TN_PLAIN;
   float* C = nullptr;   // primary output
@@ -128,6 +131,11 @@ struct TnOutput {
   int Cin = 0, Cout = 0;
   int extra_row = 0, extra_col = 0;  // TN_PLAIN: last row / column is the implicit-ones one -> C2
   int accumulate = 0;   // != 0: add to what C / C2 hold (gradient accumulation) instead of overwriting
+  // TN_RPRIME ([x | 1]^T [r | dp | dcs]): C = dlin, C2 = dbias, C3 = du, C4 = dc; col0 = first input channel of
+  // this A operand (split inputs issue one GEMM per half)
+  float* C3 = nullptr;
+  float* C4 = nullptr;
+  int col0 = 0;
 };
 // I, J: logical output sizes INCLUDING an implicit ones row / column when ones_row / ones_col >= 0
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,

@@ -393,42 +393,45 @@ __global__ __launch_bounds__(256) void feast_du_edge_kernel(const float* __restr
                                                             const int* __restrict__ col, const float* __restrict__ dl,
                                                             const float* __restrict__ dcs, int ld_dcs, int N,
                                                             float* __restrict__ partial) {
+  // LP = LC / 3 lanes per node, 3 input channels (27 accumulators) each; 256 / LP nodes per block
+  constexpr int LP = LC / 3;
   constexpr int NV = H * LC + H;
   __shared__ float red[4][NV];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float acc[H][LC], dca[H];
+  const int i = blockIdx.x * (256 / LP) + threadIdx.x / LP;
+  const int part = threadIdx.x % LP;
+  float acc[H][3], dca[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     dca[h] = 0.f;
 #pragma unroll
-    for (int k = 0; k < LC; ++k) acc[h][k] = 0.f;
+    for (int k = 0; k < 3; ++k) acc[h][k] = 0.f;
   }
   if (i < N) {
-    float xc[LC];
-    load_row<LC>(x + (size_t)i * LC, xc);
-    load_hp(dcs + (size_t)i * ld_dcs, dca);
+    const float* xi = x + (size_t)i * LC + 3 * part;
+    const float xc[3] = {xi[0], xi[1], xi[2]};
+    if (part == 0) load_hp(dcs + (size_t)i * ld_dcs, dca);
     const int rs = rowptr[i], re = rowptr[i + 1];
     for (int e = rs; e < re; ++e) {
-      float d[LC], g[H];
-      load_row<LC>(x + (size_t)col[e] * LC, d);
+      const float* xj = x + (size_t)col[e] * LC + 3 * part;
+      float g[H];
       load_hp(dl + (size_t)e * HP, g);
-#pragma unroll
-      for (int k = 0; k < LC; ++k) d[k] -= xc[k];
+      const float d[3] = {xj[0] - xc[0], xj[1] - xc[1], xj[2] - xc[2]};
 #pragma unroll
       for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int k = 0; k < LC; ++k) acc[h][k] = fmaf(g[h], d[k], acc[h][k]);
+        for (int k = 0; k < 3; ++k) acc[h][k] = fmaf(g[h], d[k], acc[h][k]);
     }
   }
+  // lanes with the same `part` hold the same channels: butterfly over the node bits of the lane id only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
 #pragma unroll
-    for (int k = 0; k < LC; ++k) {
+    for (int k = 0; k < 3; ++k) {
       float v = acc[h][k];
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[wave][h * LC + k] = v;
+      for (int o = 32; o >= LP; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LP) red[wave][h * LC + 3 * lane + k] = v;
     }
     float v = dca[h];
 #pragma unroll
@@ -443,11 +446,14 @@ __global__ __launch_bounds__(256) void feast_du_edge_kernel(const float* __restr
 
 __global__ void feast_du_final_kernel(const float* __restrict__ partial, int blocks, int LCn, int accumulate,
                                       float* __restrict__ du, float* __restrict__ dc) {
+  // one wave per output value: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed butterfly
   const int NV = H * LCn + H;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= NV) return;
+  const int t = blockIdx.x, lane = threadIdx.x;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * NV + t];
+  for (int b = lane; b < blocks; b += 64) s += partial[(size_t)b * NV + t];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane != 0) return;
   float* dst = t < H * LCn ? du + t : dc + (t - H * LCn);
   *dst = accumulate ? *dst + s : s;
 }
@@ -601,17 +607,14 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     const size_t plain = feast_wpack_plain_floats(Cin, Cout);
     float* bf = wf_out ? wf_out + plain : a.take<float>(feast_fused_fwd_pack_floats(Cin, Cout));
     GEOBI_REQUIRE(a.ok() && bf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, bf, s));
-    if (wf_out != nullptr) {      // the backward's packed forms: Wf, W' and the fused dx weights
-      const int ldr_ = feast_ldr(Cout);
-      pack_weights_kernel<<<cdiv((int64_t)Kp * Cout + (int64_t)ldr_ * Cin, 256), 256, 0, s>>>(
-          lin_w, u_w, Cin, Cout, Kp, ldr_, wf_out, wf_out + (size_t)Kp * Cout);
-      GEOBI_LAUNCH_OK();
-      GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, Cin, Cout, bf + feast_fused_fwd_pack_floats(Cin, Cout), s));
+    if (wf_out != nullptr) {      // + the backward's packed forms (Wf for dz, the fused dx weights), one launch
+      GEOBI_TRY(feast_fused_pack_all(lin_w, u_w, Cin, Cout, Kp, wf_out, bf, bf + feast_fused_fwd_pack_floats(Cin, Cout), s));
+    } else {
+      GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, bf, s));
     }
     const int LCf = edge_logit_channels(Cin, Cb);
     if (LCf == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
-    prof_begin(PROF_AGG_FWD, s, feast_fused_bytes(N, Ecap, Cin, Cout), Cin);
+    prof_begin(PROF_AGG_FWD, s, feast_fused_bytes(N, Ecap, Cin, Cout), Cin * 1000 + Cout);
     int rcf = feast_fused_fwd(xa, xb ? xb : xa, Cb ? Ca : Cin, Cin, p, cvec, rowptr_in, col_in, (int)N, LCf, u_w, bf,
                               Cout, bias, slope, out, s);
     prof_end(PROF_AGG_FWD, s);
@@ -649,9 +652,9 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
 
 struct BwdPlan {
   size_t total;
-  float *g, *wf, *dz, *dl, *dpn, *rp, *wp, *z, *bdx;
-  void *tn_ws, *tn_ws2, *gemm_ws;
-  size_t tn_bytes, tn_bytes2, gemm_bytes;
+  float *g, *wf, *dz, *dl, *dpn, *rp, *wp, *z, *bdx, *dpd;
+  void *tn_ws, *tn_ws2, *tn_ws3, *gemm_ws;
+  size_t tn_bytes, tn_bytes2, tn_bytes3, gemm_bytes;
 };
 
 static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
@@ -663,13 +666,21 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
   b.dpn = a.take<float>((size_t)N * HP);
   b.rp = a.take<float>((size_t)N * ldr);
   b.wp = a.take<float>((size_t)ldr * Cin);
-  b.z = a.take<float>((size_t)N * Kp);                       // fused forward: z is recomputed here
+  b.z = a.take<float>((size_t)N * Kp);                       // fused forward, no dx wanted: z is recomputed here
+  b.dpd = a.take<float>((size_t)N * 2 * HP);                 // fused: compact [dp | dcs]
+  b.tn_bytes3 = gemm_tn_ws_bytes(Cin + 1, ldr, N);           // fused: [x | 1]^T r' (per half for split inputs:
+  if (Cin >= 2) {                                            // fewer output tiles get more slabs)
+    const size_t h1 = gemm_tn_ws_bytes(Cin / 2 + 1, ldr, N), h2 = gemm_tn_ws_bytes(Cin / 2, ldr, N);
+    if (h1 > b.tn_bytes3) b.tn_bytes3 = h1;
+    if (h2 > b.tn_bytes3) b.tn_bytes3 = h2;
+  }
+  b.tn_ws3 = a.take<char>(b.tn_bytes3);
   b.bdx = a.take<float>(feast_fused_dx_pack_floats(Cin, Cout));
   b.tn_bytes = gemm_tn_ws_bytes(Kp + 1, Cout, N);           // [z | 1]^T g   (side stream)
   b.tn_ws = a.take<char>(b.tn_bytes);
   b.tn_bytes2 = gemm_tn_ws_bytes_any_width(2 * HP, Cin + 1, N);   // [dp | dcs]^T [x | 1], per input half
   {                                                               // or the per-edge du / dc partials (level 0)
-    const size_t du_bytes = align_up((size_t)cdiv(N, 256) * (H * Cin + H) * sizeof(float)) + 256;
+    const size_t du_bytes = align_up((size_t)cdiv(N, 64) * (H * Cin + H) * sizeof(float)) + 256;
     if ((Cin == 6 || Cin == 12) && du_bytes > b.tn_bytes2) b.tn_bytes2 = du_bytes;
   }
   b.tn_ws2 = a.take<char>(b.tn_bytes2);
@@ -713,13 +724,17 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   const int LC = edge_logit_channels(Cin, Cb);
   // Fused forward (z == NULL): the aggregated rows were never written; recompute them for dW = z^T g
   const bool fused = z == nullptr;
-  if (fused) {
+  // Fused + input gradient wanted: every weight gradient comes from ONE product [x | 1]^T r' on the rows r' the dx
+  // kernel forms anyway (dW[h,k,o] = sum_j x_j[k] r_j[h,o]): no z needed.  Without dx (first layer of the vertex
+  // branch) z is recomputed by the aggregation kernel for dW = z^T g.
+  const bool rform = fused && dxa != nullptr;
+  if (fused && !rform) {
     GEOBI_TRY(launch_aggregate<0>(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, nullptr, (int)N, b.z, Kp, LC, xa, u_w, s));
     z = b.z;
   }
   // 2'. weight + bias gradient [z | 1]^T g: needs only z and g, nothing downstream needs it -> side stream
   Fork fk = fork_side_stream(s);
-  {
+  if (!rform) {
     TnOutput ow;
     ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout; ow.accumulate = accumulate;
     GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, fk.side ? fk.side : s));
@@ -738,7 +753,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   // 3. row pass: per-edge softmax backward
   prof_begin(PROF_ROWPASS, s, 0.0, Cin);
   // [dp | dcs]: the tail columns of r' (unfused dx GEMM) or a compact [N, 24] array (fused dx kernel)
-  float* dpd = fused ? b.rp : b.rp + H * Cout;
+  float* dpd = fused ? b.dpd : b.rp + H * Cout;
   const int ld_dpd = fused ? 2 * HP : ldr;
   int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,
                           dpd + HP, ld_dpd, LC, u_w, s);
@@ -753,7 +768,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     // per-edge du / dc (see feast_du_edge_kernel); needs dl and dcs only -> side stream as well
     GEOBI_TRY(side_wait_main(fk, s));
     hipStream_t ss = fk.side ? fk.side : s;
-    const int blocks = cdiv(N, 256);
+    const int blocks = cdiv(N, 256 / (LC / 3));
     float* partial = (float*)b.tn_ws2;
     GEOBI_REQUIRE((size_t)blocks * (H * LC + H) * sizeof(float) <= b.tn_bytes2, "feast_bwd: du workspace too small");
     if (LC == 6)
@@ -761,9 +776,9 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     else
       feast_du_edge_kernel<12><<<blocks, 256, 0, ss>>>(xa, rowptr_in, col_in, b.dl, dpd + HP, ld_dpd, (int)N, partial);
     GEOBI_LAUNCH_OK();
-    feast_du_final_kernel<<<1, 128, 0, ss>>>(partial, blocks, LC, accumulate, du_w, dc);
+    feast_du_final_kernel<<<H * LC + H, 64, 0, ss>>>(partial, blocks, LC, accumulate, du_w, dc);
     GEOBI_LAUNCH_OK();
-  } else {
+  } else if (!rform) {
     GEOBI_TRY(side_wait_main(fk, s));
     hipStream_t ss = fk.side ? fk.side : s;
     TnOutput ou;
@@ -784,9 +799,21 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     }
     prof_begin(PROF_AGG_BWD, s, feast_fused_bytes(N, Ecap, Cout, Cin), Cout);
     rc = feast_fused_dx(g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, LC, xa, u_w, dpd, bdx, Cin, dxa,
-                        Cb ? Ca : Cin, dxb, Cb, s);
+                        Cb ? Ca : Cin, dxb, Cb, b.rp, s);
     prof_end(PROF_AGG_BWD, s);
     GEOBI_TRY(rc);
+    // every weight gradient of the layer: [x | 1]^T r' (side stream; du / dc of the per-edge-logit layers come from
+    // feast_du_edge_kernel above instead)
+    GEOBI_TRY(side_wait_main(fk, s));
+    hipStream_t ss = fk.side ? fk.side : s;
+    TnOutput o;
+    o.mode = TN_RPRIME; o.C = dlin_w; o.C2 = dbias; o.C3 = LC ? nullptr : du_w; o.C4 = LC ? nullptr : dc;
+    o.Cin = Cin; o.Cout = Cout; o.col0 = 0; o.extra_row = 1; o.accumulate = accumulate;
+    GEOBI_TRY(gemm_tn(xa, Ca_, b.rp, ldr, N, Ca_ + 1, ldr, Ca_, -1, o, b.tn_ws3, b.tn_bytes3, ss));
+    if (Cb) {
+      o.col0 = Ca; o.extra_row = 0; o.C2 = nullptr; o.C4 = nullptr;
+      GEOBI_TRY(gemm_tn(xb, Cb, b.rp, ldr, N, Cb, ldr, -1, -1, o, b.tn_ws3, b.tn_bytes3, ss));
+    }
   } else if (dxa != nullptr) {
     prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);
     rc = launch_aggregate<1>(Cout, g, g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, b.rp, ldr, LC, xa, u_w,

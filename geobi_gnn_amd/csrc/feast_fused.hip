@@ -37,212 +37,311 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TN = 32;        // nodes per tile = rows of one MFMA tile
 constexpr int NW = 8;         // waves per workgroup
 constexpr int RED_LD = 36;    // row stride of a partial output tile in LDS
+constexpr int G = 16;         // lanes per node in the gather phase: a wave owns 4 nodes, the 8 waves the 32 of a tile
+constexpr int NPW = 64 / G;
+static_assert(NW * NPW == TN, "one gather pass covers the tile");
 
-__host__ __device__ constexpr int tile_ld(int K) { return (K - 4 + 63) / 64 * 64 + 4; }
-__host__ __device__ constexpr int fused_k(int C, int MODE) { return MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP; }
-__host__ __device__ constexpr int fused_lds_floats(int C, int MODE, int LC) {
-  const int tile = TN * tile_ld(fused_k(C, MODE)), red = NW * 32 * RED_LD;
-  return (tile > red ? tile : red) + (LC > 0 ? LC * HP : 0);
+// Shape of one instantiation.  C = width of the gathered rows; MODE 0: K = 9 C (padded to 8), MODE 1: 9 C + 24.
+// The 16 lanes of a node split the C channels: VEC floats per lane in NP pieces of PV floats (C = 128: two
+// 16-B pieces, channels [4k, 4k+4) and [64 + 4k, ..), so every load instruction still covers one contiguous
+// 256-B segment of the row); C = 6 / 12: one float on the first C lanes.
+// C = 128 does not fit a [32][9 C] tile twice into a CU's LDS: the tile then holds HC = 4 heads at a time
+// (3 chunks: 4 + 4 + 1 heads), the node's 9 x VEC accumulators wait in registers, and the MFMA accumulators run
+// across the chunks.
+template <int C, int MODE>
+struct Shape {
+  static constexpr int VEC = C >= 16 ? C / 16 : 1;
+  static constexpr int NP = VEC > 4 ? VEC / 4 : 1;
+  static constexpr int PV = VEC / NP;
+  static constexpr int ACTIVE = C >= 16 ? 16 : C;                 // lanes of the group that own channels
+  static constexpr int HC = C >= 128 ? 4 : H;                     // heads per LDS chunk
+  static constexpr int NCHUNK = (H + HC - 1) / HC;
+  static constexpr int KD = MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP;     // K of the whole product
+  static constexpr int KC_FULL = HC * C;                          // chunk width (all but the last chunk)
+  static constexpr int KC_LAST = KD - (NCHUNK - 1) * KC_FULL;
+  static constexpr int KC_MAX = NCHUNK == 1 ? KD : (KC_FULL > KC_LAST ? KC_FULL : KC_LAST);
+  static constexpr int LD = (KC_MAX - 4 + 63) / 64 * 64 + 4;      // = 4 mod 64: conflict-free ds_read_b128 of A
+  static constexpr bool SLOT_IN_ROW = G * HP <= (NCHUNK == 1 ? H * C : KC_FULL);
+  static constexpr int TILE_FLOATS = TN * LD > NW * 32 * RED_LD ? TN * LD : NW * 32 * RED_LD;
+  static constexpr int SLOT_FLOATS = SLOT_IN_ROW ? 0 : NW * 64 * HP;
+  static_assert(VEC * ACTIVE == C || C < 16, "channel split");
+  static_assert(KD % 8 == 0 && (NCHUNK == 1 || KC_FULL % 8 == 0) && KC_LAST % 8 == 0 && KC_LAST > 0, "whole k-blocks per chunk");
+};
+template <int C, int MODE, int LC>
+constexpr int fused_lds_floats() { return Shape<C, MODE>::TILE_FLOATS + Shape<C, MODE>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0); }
+constexpr int fused_k(int C, int MODE) { return MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP; }
+
+// One lane's share of a row: PV floats per piece
+template <int PV>
+__device__ __forceinline__ void load_piece(const float* __restrict__ ptr, float* v) {
+  if constexpr (PV == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(ptr);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (PV == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(ptr);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = ptr[0];
+  }
+}
+template <int PV>
+__device__ __forceinline__ void store_piece(float* ptr, const float* v) {
+  if constexpr (PV == 4) *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (PV == 2) *reinterpret_cast<float2*>(ptr) = make_float2(v[0], v[1]);
+  else ptr[0] = v[0];
 }
 
-template <int C, int VEC, int MODE, int LC, int NT>
-__global__ __launch_bounds__(512) void feast_fused_kernel(
+#ifdef GEOBI_FUSED_STAMPS
+// Diagnostic build only (tools/build_variant.sh ... -DGEOBI_FUSED_STAMPS): shader-clock stamps of wave 0 of each
+// workgroup at the phase boundaries, written to a buffer nothing else reads.
+__device__ unsigned long long g_stamps[16384][8];
+#define GEOBI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEOBI_STAMP(i) do { } while (0)
+#endif
+
+template <int C, int MODE, int LC, int NT>
+__global__ __launch_bounds__(512, 4) void feast_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
     const int* __restrict__ deg_rowptr, int N, const float* __restrict__ xl, const float* __restrict__ ul,
     const float* __restrict__ dpd, const float* __restrict__ Bp, int NOUT, const float* __restrict__ bias,
-    float slope, float* __restrict__ out, int ldo, float* __restrict__ out1, int split, int ldo1) {
-  constexpr int G = C / VEC;
-  constexpr int NPW = 64 / G;
-  constexpr int KD = fused_k(C, MODE);
-  constexpr int LD = tile_ld(KD);
-  static_assert(G * VEC == C && G >= 2 && (64 % G) == 0, "group shape");
-  static_assert(G * HP <= H * C, "the parking slots of a node fit its own tile row");
-  static_assert(MODE == 0 || G >= 6, "the [dp | dcs] columns are copied by 6 lanes of the group");
+    float slope, float* __restrict__ out, int ldo, float* __restrict__ out1, int split, int ldo1,
+    float* __restrict__ tile_out) {
+  using S = Shape<C, MODE>;
+  constexpr int VEC = S::VEC, NP = S::NP, PV = S::PV, LD = S::LD, HC = S::HC, NCHUNK = S::NCHUNK;
   static_assert(NW % NT == 0, "column tiles divide the waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TILE_FLOATS = TN * LD > NW * 32 * RED_LD ? TN * LD : NW * 32 * RED_LD;
-  float* s_u = smem + TILE_FLOATS;
+  float* s_slots = smem + S::TILE_FLOATS;
+  float* s_u = s_slots + S::SLOT_FLOATS;
   if constexpr (LC > 0) stage_u<LC>(ul, s_u);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = xcd_block(blockIdx.x, gridDim.x);
   if (tile * TN >= N) return;          // whole workgroup: surplus tile of the XCD-padded grid
 
-  // ------------------------------------------------------------------ phase A: aggregate into the LDS tile
+  GEOBI_STAMP(0);
+  // ------------------------------------------------------------------ phase A: aggregate into registers
+  const int g = lane / G, k = lane % G;
+  const int nl = wave * NPW + g;                 // node within the tile
+  const int node = tile * TN + nl;
+  const bool valid = node < N;
+  float* zrow = smem + nl * LD;
+  float acc[H][VEC];
   {
-    const int g = lane / G, k = lane % G;
-    const int c0 = k * VEC;
-    const float* fbase;
-    int fstride;
-    if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
+    const bool act = k < S::ACTIVE;              // lanes that own channels (C = 6 / 12: the first C)
+    const float* fb[NP];
+    int fs[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int c0 = act ? q * (C / NP) + k * PV : 0;
+      if (c0 < Ca) { fb[q] = xa + c0; fs[q] = Ca; } else { fb[q] = xb + (c0 - Ca); fs[q] = C - Ca; }
+    }
     float cc[H], qs[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
     softmax9(qs);   // the self edge: u(x_i - x_i) + c = c exactly
 
-    for (int nb = wave * NPW; nb < TN; nb += NW * NPW) {
-      const int nl = nb + g;
-      const int node = tile * TN + nl;
-      const bool valid = node < N;
-      const int ns = valid ? node : N - 1;
-      const int rs = rowptr[ns];
-      const int re = valid ? rowptr[ns + 1] : rs;
-      float* zrow = smem + nl * LD;
-      float(*slot)[HP] = reinterpret_cast<float(*)[HP]>(zrow);
-
-      float pc[H];
-      float xc[LC > 0 ? LC : 1];
-      if constexpr (LC > 0) load_row<LC>(xl + (size_t)ns * LC, xc);
-      else load_hp(p + (size_t)ns * HP, pc);
-
-      float acc[H][VEC];
+    const int ns = valid ? node : N - 1;
+    const int rs = rowptr[ns];
+    const int re = valid ? rowptr[ns + 1] : rs;
+    float(*slot)[HP] = S::SLOT_IN_ROW ? reinterpret_cast<float(*)[HP]>(zrow)
+                                      : reinterpret_cast<float(*)[HP]>(s_slots + (wave * 64 + g * G) * HP);
+    float pc[H];
+    float xc[LC > 0 ? LC : 1];
+    if constexpr (LC > 0) load_row<LC>(xl + (size_t)ns * LC, xc);
+    else load_hp(p + (size_t)ns * HP, pc);
+    {
+      float xs[VEC];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) load_piece<PV>(fb[q] + (size_t)ns * fs[q], xs + q * PV);
+      float sscale = 1.0f;
+      if constexpr (MODE == 1) sscale = 1.0f / (float)(deg_rowptr[ns + 1] - deg_rowptr[ns] + 1);
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[h][v] = qs[h] * sscale * xs[v];
+    }
+    for (int base = rs; base < re; base += G) {
+      // ---- lane k of the group handles edge base + k: logits, softmax, park q and the neighbour id
       {
-        float xs[VEC];
-        load_vec<VEC>(fbase + (size_t)ns * fstride, xs);
-        float sscale = 1.0f;
-        if constexpr (MODE == 1) sscale = 1.0f / (float)(deg_rowptr[ns + 1] - deg_rowptr[ns] + 1);
+        const int e = base + k;
+        float q[H];
+        int j = ns;
+        if (e < re) {
+          j = col[e];
+          if constexpr (LC > 0) {
+            float d[LC];
+            load_row<LC>(xl + (size_t)j * LC, d);
 #pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[h][v] = qs[h] * sscale * xs[v];
-      }
-
-      for (int base = rs; base < re; base += G) {
-        // ---- lane k of the group handles edge base + k: logits, softmax, park q and the neighbour id
-        {
-          const int e = base + k;
-          float q[H];
-          int j = ns;
-          if (e < re) {
-            j = col[e];
-            if constexpr (LC > 0) {
-              float d[LC];
-              load_row<LC>(xl + (size_t)j * LC, d);
-#pragma unroll
-              for (int i = 0; i < LC; ++i) d[i] = (MODE == 0) ? (d[i] - xc[i]) : (xc[i] - d[i]);
-              edge_logits<LC>(d, s_u, cc, q);
-            } else {
-              float pn[H];
-              load_hp(p + (size_t)j * HP, pn);
-#pragma unroll
-              for (int h = 0; h < H; ++h) q[h] = (MODE == 0) ? (pn[h] - pc[h] + cc[h]) : (pc[h] - pn[h] + cc[h]);
-            }
-            softmax9(q);
-            if constexpr (MODE == 1) {
-              float w = 1.0f / (float)(deg_rowptr[j + 1] - deg_rowptr[j] + 1);
-#pragma unroll
-              for (int h = 0; h < H; ++h) q[h] *= w;
-            }
+            for (int i = 0; i < LC; ++i) d[i] = (MODE == 0) ? (d[i] - xc[i]) : (xc[i] - d[i]);
+            edge_logits<LC>(d, s_u, cc, q);
           } else {
+            float pn[H];
+            load_hp(p + (size_t)j * HP, pn);
 #pragma unroll
-            for (int h = 0; h < H; ++h) q[h] = 0.f;
+            for (int h = 0; h < H; ++h) q[h] = (MODE == 0) ? (pn[h] - pc[h] + cc[h]) : (pc[h] - pn[h] + cc[h]);
           }
-          float4* dst = reinterpret_cast<float4*>(slot[k]);
-          dst[0] = make_float4(q[0], q[1], q[2], q[3]);
-          dst[1] = make_float4(q[4], q[5], q[6], q[7]);
-          dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
+          softmax9(q);
+          if constexpr (MODE == 1) {
+            float w = 1.0f / (float)(deg_rowptr[j + 1] - deg_rowptr[j] + 1);
+#pragma unroll
+            for (int h = 0; h < H; ++h) q[h] *= w;
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] = 0.f;
         }
-        wave_lds_sync();
-        // ---- all G lanes of the group walk the parked edges, two at a time
-        const int cnt = min(G, re - base);
-        for (int t = 0; t < cnt; t += 2) {
-          const float4* s0 = reinterpret_cast<const float4*>(slot[t]);
-          const float4* s1 = reinterpret_cast<const float4*>(slot[t + 1]);
-          float4 a0 = s0[0], b0 = s0[1], d0 = s0[2];
-          float4 a1 = s1[0], b1 = s1[1], d1 = s1[2];
-          float x0[VEC], x1[VEC];
-          load_vec<VEC>(fbase + (size_t)__float_as_int(d0.y) * fstride, x0);
-          load_vec<VEC>(fbase + (size_t)__float_as_int(d1.y) * fstride, x1);
-          const float q0[H] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x};
-          const float q1[H] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w, d1.x};
-#pragma unroll
-          for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[h][v] = fmaf(q0[h], x0[v], acc[h][v]);
-#pragma unroll
-          for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[h][v] = fmaf(q1[h], x1[v], acc[h][v]);
-        }
-        wave_lds_sync();
+        float4* dst = reinterpret_cast<float4*>(slot[k]);
+        dst[0] = make_float4(q[0], q[1], q[2], q[3]);
+        dst[1] = make_float4(q[4], q[5], q[6], q[7]);
+        dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
       }
+      wave_lds_sync();
+      GEOBI_STAMP(1);
+      // ---- the lanes that own channels walk the parked edges, UNR at a time (surplus slots hold q = 0, j = ns)
+#ifdef GEOBI_FUSED_UNR
+      constexpr int UNR = GEOBI_FUSED_UNR;          // tuning builds (tools/build_variant.sh)
+#else
+      constexpr int UNR = VEC < 4 ? 4 : 2;
+#endif
+      const int cnt = min(G, re - base);
+      if (act) {
+        for (int t = 0; t < cnt; t += UNR) {
+          // UNR neighbour rows in flight; the parked q of an edge is read (LDS broadcast) right before its FMAs
+          float xv[UNR][VEC];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int jn = __float_as_int(slot[t + u][H]);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) load_piece<PV>(fb[q] + (size_t)jn * fs[q], xv[u] + q * PV);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const float4* sp = reinterpret_cast<const float4*>(slot[t + u]);
+            const float4 a = sp[0], b = sp[1];
+            const float q8 = slot[t + u][8];
+            const float qq[H] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, q8};
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[h][v] = fmaf(qq[h], xv[u][v], acc[h][v]);
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    GEOBI_STAMP(2);
+    float scale = valid ? 1.0f : 0.0f;
+    if constexpr (MODE == 0) scale = valid ? 1.0f / (float)(re - rs + 1) : 0.0f;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[h][v] *= scale;
+  }
 
-      // ---- the node's aggregated row replaces its parking slots
-      float scale = valid ? 1.0f : 0.0f;
-      if constexpr (MODE == 0) scale = valid ? 1.0f / (float)(re - rs + 1) : 0.0f;
+  // ------------------------------------------------------------------ chunks: registers -> LDS tile -> MFMA
+  constexpr int KS = NW / NT;
+  const int ct = wave % NT, ks = wave / NT;
+  const int hf = lane >> 5, l31 = lane & 31;
+  f32x16 macc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) macc[r] = 0.f;
+
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int nheads = (c == NCHUNK - 1) ? H - c * HC : HC;
+    // ---- this lane's slices of heads [c HC, c HC + nheads) -> its node's tile row
+    if (k < S::ACTIVE) {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float v[VEC];
+        if (h / HC != c) continue;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) v[i] = acc[h][i] * scale;
-        store_vec<VEC>(zrow + h * C + c0, v);
+        for (int q = 0; q < NP; ++q)
+          store_piece<PV>(zrow + (h - c * HC) * C + q * (C / NP) + k * PV, &acc[h][q * PV]);
       }
+    }
+    if (c == NCHUNK - 1) {
       if constexpr (MODE == 0) {
-        for (int i = H * C + k; i < KD; i += G) zrow[i] = 0.f;          // K padding
+        for (int i = nheads * C + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding (C = 6 / 12)
       } else {
-        if (k < 6) {                                                    // [dp | dcs]: 24 floats
+        if (k < 6) {                                                                // [dp | dcs]: 24 floats
           float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
           if (valid) t = reinterpret_cast<const float4*>(dpd + (size_t)node * (2 * HP))[k];
-          reinterpret_cast<float4*>(zrow + H * C)[k] = t;
+          reinterpret_cast<float4*>(zrow + nheads * C)[k] = t;
         }
       }
     }
-  }
-  __syncthreads();
-
-  // ------------------------------------------------------------------ phase B: tile x packed weights on MFMA
-  constexpr int NKB = KD / 8;
-  constexpr int KS = NW / NT;
-  constexpr int KB_PER = (NKB + KS - 1) / KS;
-  const int ct = wave % NT, ks = wave / NT;
-  const int kb0 = ks * KB_PER;
-  const int kb1 = min(NKB, kb0 + KB_PER);
-  const int hf = lane >> 5, l31 = lane & 31;
-  f32x16 acc;
+    // ---- tile chunk x packed weights on the matrix cores.  The weights of a wave's k-range come from L2 in
+    // batches of BATCH k-blocks (one 16-B load per lane and block = 4 MFMAs): the first batch is requested BEFORE
+    // the barrier that publishes the tile, every further one a whole batch (256 BATCH pipe cycles) ahead of its
+    // use, so the matrix pipe never waits on L2 latency; the A operand is read from LDS one block ahead.
+    {
+      constexpr int BATCH = VEC >= 8 ? 4 : 8;
+      const int nkb = ((c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL) / 8;
+      const int kb_base = c * (S::KC_FULL / 8);
+      const int kb_per = (nkb + KS - 1) / KS;
+      const int kb0 = ks * kb_per;
+      const int kb1 = min(nkb, kb0 + kb_per);
+      const bool work = kb0 < kb1;
+      const float* arow = smem + l31 * LD + 4 * hf;
+      const float4* bcol = reinterpret_cast<const float4*>(Bp) + (size_t)kb_base * (2 * 32 * NT) +
+                           (size_t)hf * (32 * NT) + ct * 32 + l31;
+      float4 w_cur[BATCH], w_nxt[BATCH];
+      auto load_w = [&](float4 (&wv)[BATCH], int b) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (kb0 < kb1) {
-    // two k-blocks (8 MFMAs, 512 pipe cycles) per stage; the next stage's LDS and L2 loads are issued before
-    // this stage's MFMAs (clamped block index: always a valid address, surplus blocks are skipped below)
-    constexpr int U = 2;
-    const float* arow = smem + l31 * LD + 4 * hf;
-    const float4* bcol = reinterpret_cast<const float4*>(Bp) + (size_t)hf * (32 * NT) + ct * 32 + l31;
-    float4 a_cur[U], w_cur[U], a_nxt[U], w_nxt[U];
-    auto load = [&](float4 (&av)[U], float4 (&wv)[U], int b) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int bb = min(b + u, kb1 - 1);
-        av[u] = *reinterpret_cast<const float4*>(arow + 8 * bb);
-        wv[u] = bcol[(size_t)bb * (2 * 32 * NT)];
-      }
-    };
-    load(a_cur, w_cur, kb0);
-    for (int b = kb0; b < kb1; b += U) {
-      load(a_nxt, w_nxt, b + U);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (b + u < kb1) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].x, w_cur[u].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].y, w_cur[u].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].z, w_cur[u].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].w, w_cur[u].w, acc, 0, 0, 0);
+        for (int u = 0; u < BATCH; ++u) wv[u] = bcol[(size_t)min(b + u, kb1 - 1) * (2 * 32 * NT)];
+      };
+      if (work) load_w(w_cur, kb0);
+      GEOBI_STAMP(3);
+      __syncthreads();
+      GEOBI_STAMP(4);
+      if (tile_out != nullptr) {
+        // the tile rows themselves (MODE 1: r' = [r | dp | dcs]) for the weight-gradient GEMM [x | 1]^T r'
+        const int kc = (c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL;
+        const int q4 = kc >> 2;                                    // float4 per row of this chunk
+        for (int i = threadIdx.x; i < TN * q4; i += 512) {
+          const int r = i / q4, c4 = (i - r * q4) * 4;
+          const int gn = tile * TN + r;
+          if (gn < N)
+            *reinterpret_cast<float4*>(tile_out + (size_t)gn * S::KD + c * S::KC_FULL + c4) =
+                *reinterpret_cast<const float4*>(smem + r * LD + c4);
         }
       }
+      if (work) {
+        float4 a = *reinterpret_cast<const float4*>(arow + 8 * kb0);
+        for (int b = kb0; b < kb1; b += BATCH) {
+          load_w(w_nxt, b + BATCH);                 // clamped: always a valid address
 #pragma unroll
-      for (int u = 0; u < U; ++u) { a_cur[u] = a_nxt[u]; w_cur[u] = w_nxt[u]; }
+          for (int u = 0; u < BATCH; ++u) {
+            const float4 an = *reinterpret_cast<const float4*>(arow + 8 * min(b + u + 1, kb1 - 1));
+            if (b + u < kb1) {
+              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w_cur[u].x, macc, 0, 0, 0);
+              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w_cur[u].y, macc, 0, 0, 0);
+              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w_cur[u].z, macc, 0, 0, 0);
+              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w_cur[u].w, macc, 0, 0, 0);
+            }
+            a = an;
+          }
+#pragma unroll
+          for (int u = 0; u < BATCH; ++u) w_cur[u] = w_nxt[u];
+        }
+      }
     }
+    GEOBI_STAMP(5);
+    __syncthreads();                               // every wave is done reading this chunk of the tile
+    GEOBI_STAMP(6);
   }
-  __syncthreads();                                 // every wave is done reading the z tile
   float(*red)[32][RED_LD] = reinterpret_cast<float(*)[32][RED_LD]>(smem);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][l31] = acc[r];
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][l31] = macc[r];
   __syncthreads();
 
   // ------------------------------------------------------------------ epilogue: fold the K splits, store
   const int row = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;
-  const int node = tile * TN + row;
-  if (node >= N) return;
+  const int onode = tile * TN + row;
+  GEOBI_STAMP(7);
+  if (onode >= N) return;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float2 s = make_float2(0.f, 0.f);
@@ -257,15 +356,15 @@ __global__ __launch_bounds__(512) void feast_fused_kernel(
       s.x += bias[cidx]; s.y += bias[cidx + 1];
       s.x = s.x > 0.f ? s.x : s.x * slope;
       s.y = s.y > 0.f ? s.y : s.y * slope;
-      *reinterpret_cast<float2*>(out + (size_t)node * ldo + cidx) = s;
+      *reinterpret_cast<float2*>(out + (size_t)onode * ldo + cidx) = s;
     } else {
       const float v2[2] = {s.x, s.y};
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int cc_ = cidx + i;
         if (cc_ >= NOUT) continue;
-        if (out1 != nullptr && cc_ >= split) out1[(size_t)node * ldo1 + (cc_ - split)] = v2[i];
-        else out[(size_t)node * ldo + cc_] = v2[i];
+        if (out1 != nullptr && cc_ >= split) out1[(size_t)onode * ldo1 + (cc_ - split)] = v2[i];
+        else out[(size_t)onode * ldo + cc_] = v2[i];
       }
     }
   }
@@ -302,44 +401,88 @@ __global__ void pack_fused_dx_kernel(const float* __restrict__ lin_w, const floa
   bp[idx] = v;
 }
 
-template <int C, int VEC, int MODE, int LC, int NT>
+// Training forward: every packed form the layer's forward AND backward need, in one launch --
+//   wf  [Kp, Cout]      row h Cin + k = lin.weight[h Cout + o, k]      (dz = g Wf^T in the backward)
+//   bf  fragment-ordered forward weights (pack_fused_fwd_kernel),  bdx  fragment-ordered dx weights.
+__global__ void pack_fused_all_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w, int Cin, int Cout,
+                                      int Kp, int KDf, int NPf, int KDx, int NPx, float* __restrict__ wf,
+                                      float* __restrict__ bf, float* __restrict__ bdx) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_wf = Kp * Cout, n_bf = KDf * NPf, n_bx = KDx * NPx;
+  if (idx < n_wf) {
+    const int kk = idx / Cout, o = idx % Cout;
+    const int h = kk / Cin, k = kk % Cin;
+    wf[idx] = (h < H) ? lin_w[((size_t)h * Cout + o) * Cin + k] : 0.f;
+    return;
+  }
+  idx -= n_wf;
+  if (idx < n_bf) {
+    const int s = idx & 3, colx = (idx >> 2) % NPf, rest = (idx >> 2) / NPf;
+    const int k = 8 * (rest >> 1) + 4 * (rest & 1) + s;
+    float v = 0.f;
+    if (k < H * Cin && colx < Cout) v = lin_w[((size_t)(k / Cin) * Cout + colx) * Cin + (k % Cin)];
+    bf[idx] = v;
+    return;
+  }
+  idx -= n_bf;
+  if (idx < n_bx) {
+    const int s = idx & 3, colx = (idx >> 2) % NPx, rest = (idx >> 2) / NPx;
+    const int k = 8 * (rest >> 1) + 4 * (rest & 1) + s;
+    float v = 0.f;
+    if (colx < Cin) {
+      if (k < H * Cout) v = lin_w[(size_t)k * Cin + colx];
+      else if (k < H * Cout + H) v = u_w[(size_t)(k - H * Cout) * Cin + colx];
+    }
+    bdx[idx] = v;
+  }
+}
+
+template <int C, int MODE, int LC, int NT>
 int launch_one(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
                const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
-               int ldo1, hipStream_t s) {
-  constexpr size_t lds = (size_t)fused_lds_floats(C, MODE, LC) * sizeof(float);
+               int ldo1, float* tile_out, hipStream_t s) {
+  constexpr size_t lds = (size_t)fused_lds_floats<C, MODE, LC>() * sizeof(float);
   static_assert(lds <= 163840, "tile exceeds the LDS of a CU");
   static bool attr_set = false;
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, VEC, MODE, LC, NT>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_fused_kernel<C, VEC, MODE, LC, NT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
-      xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1);
+  feast_fused_kernel<C, MODE, LC, NT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+      xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1,
+      tile_out);
   GEOBI_LAUNCH_OK();
   return 0;
 }
 
 #define GEOBI_FUSED_ARGS                                                                                            \
-  xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1, s
+  xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1, \
+      tile_out, s
 
-template <int C, int VEC, int MODE, int LC>
+template <int C, int MODE, int LC>
 int launch_nt(int NT, const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
               const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
               const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
-              int ldo1, hipStream_t s) {
+              int ldo1, float* tile_out, hipStream_t s) {
   // dx with per-edge logits writes a 6- or 12-channel input gradient: one column tile
   constexpr bool kNarrowOnly = MODE == 1 && LC > 0;
-  if (NT == 1) return launch_one<C, VEC, MODE, LC, 1>(GEOBI_FUSED_ARGS);
+  if (NT == 1) return launch_one<C, MODE, LC, 1>(GEOBI_FUSED_ARGS);
   if constexpr (!kNarrowOnly) {
-    if (NT == 2) return launch_one<C, VEC, MODE, LC, 2>(GEOBI_FUSED_ARGS);
-    if (NT == 4) return launch_one<C, VEC, MODE, LC, 4>(GEOBI_FUSED_ARGS);
+    if (NT == 2) return launch_one<C, MODE, LC, 2>(GEOBI_FUSED_ARGS);
+    if (NT == 4) return launch_one<C, MODE, LC, 4>(GEOBI_FUSED_ARGS);
   }
   return set_error("feast fused: unsupported output width %d", NOUT);
 }
 
 }  // namespace
+
+#ifdef GEOBI_FUSED_STAMPS
+extern "C" int geobi_debug_stamps(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int feast_fused_nt(int nout) { return nout <= 32 ? 1 : (nout <= 64 ? 2 : 4); }
 size_t feast_fused_fwd_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout); }
@@ -348,6 +491,15 @@ size_t feast_fused_dx_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Co
 int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s) {
   const int KD = fused_k(Cin, 0), NP = 32 * feast_fused_nt(Cout);
   pack_fused_fwd_kernel<<<cdiv((int64_t)KD * NP, 256), 256, 0, s>>>(lin_w, Cin, Cout, KD, NP, bp);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout, int Kp, float* wf, float* bf,
+                         float* bdx, hipStream_t s) {
+  const int KDf = fused_k(Cin, 0), NPf = 32 * feast_fused_nt(Cout), KDx = fused_k(Cout, 1), NPx = 32 * feast_fused_nt(Cin);
+  const int64_t total = (int64_t)Kp * Cout + (int64_t)KDf * NPf + (int64_t)KDx * NPx;
+  pack_fused_all_kernel<<<cdiv(total, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, Kp, KDf, NPf, KDx, NPx, wf, bf, bdx);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -373,15 +525,16 @@ int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const flo
   const float* dpd = nullptr;
   const int NOUT = Cout, ldo = Cout, split = 0, ldo1 = 0;
   float* out1 = nullptr;
+  float* tile_out = nullptr;
   const int NT = feast_fused_nt(Cout);
   switch (Cin * 100 + LC) {
-    case 600: return launch_nt<6, 3, 0, 0>(NT, GEOBI_FUSED_ARGS);
-    case 606: return launch_nt<6, 3, 0, 6>(NT, GEOBI_FUSED_ARGS);
-    case 1200: return launch_nt<12, 3, 0, 0>(NT, GEOBI_FUSED_ARGS);
-    case 1212: return launch_nt<12, 3, 0, 12>(NT, GEOBI_FUSED_ARGS);
-    case 3200: return launch_nt<32, 4, 0, 0>(NT, GEOBI_FUSED_ARGS);
-    case 6400: return launch_nt<64, 4, 0, 0>(NT, GEOBI_FUSED_ARGS);
-    case 12800: return launch_nt<128, 4, 0, 0>(NT, GEOBI_FUSED_ARGS);
+    case 600: return launch_nt<6, 0, 0>(NT, GEOBI_FUSED_ARGS);
+    case 606: return launch_nt<6, 0, 6>(NT, GEOBI_FUSED_ARGS);
+    case 1200: return launch_nt<12, 0, 0>(NT, GEOBI_FUSED_ARGS);
+    case 1212: return launch_nt<12, 0, 12>(NT, GEOBI_FUSED_ARGS);
+    case 3200: return launch_nt<32, 0, 0>(NT, GEOBI_FUSED_ARGS);
+    case 6400: return launch_nt<64, 0, 0>(NT, GEOBI_FUSED_ARGS);
+    case 12800: return launch_nt<128, 0, 0>(NT, GEOBI_FUSED_ARGS);
     default: return set_error("feast fused forward: unsupported Cin=%d (per-edge logit channels %d)", Cin, LC);
   }
 }
@@ -389,7 +542,8 @@ int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const flo
 // backward: (dxa | dxb) = [r | dp | dcs] W', r aggregated over the transposed CSR from g [N, Cout]
 int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, const int* rowptr_out,
                    const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
-                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, hipStream_t s) {
+                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
+                   hipStream_t s) {
   const float *xa = g, *xb = g;
   const int* rowptr = rowptr_out;
   const int* col = col_out;
@@ -403,15 +557,15 @@ int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, 
   const int NT = feast_fused_nt(Cin);
   Ca = Cout;                      // the gathered rows are the unsplit g
   switch (Cout * 100 + LC) {
-    case 3200: return launch_nt<32, 4, 1, 0>(NT, GEOBI_FUSED_ARGS);
-    case 3206: return launch_nt<32, 4, 1, 6>(NT, GEOBI_FUSED_ARGS);
-    case 3212: return launch_nt<32, 4, 1, 12>(NT, GEOBI_FUSED_ARGS);
-    case 6400: return launch_nt<64, 4, 1, 0>(NT, GEOBI_FUSED_ARGS);
-    case 6406: return launch_nt<64, 4, 1, 6>(NT, GEOBI_FUSED_ARGS);
-    case 6412: return launch_nt<64, 4, 1, 12>(NT, GEOBI_FUSED_ARGS);
-    case 12800: return launch_nt<128, 4, 1, 0>(NT, GEOBI_FUSED_ARGS);
-    case 12806: return launch_nt<128, 4, 1, 6>(NT, GEOBI_FUSED_ARGS);
-    case 12812: return launch_nt<128, 4, 1, 12>(NT, GEOBI_FUSED_ARGS);
+    case 3200: return launch_nt<32, 1, 0>(NT, GEOBI_FUSED_ARGS);
+    case 3206: return launch_nt<32, 1, 6>(NT, GEOBI_FUSED_ARGS);
+    case 3212: return launch_nt<32, 1, 12>(NT, GEOBI_FUSED_ARGS);
+    case 6400: return launch_nt<64, 1, 0>(NT, GEOBI_FUSED_ARGS);
+    case 6406: return launch_nt<64, 1, 6>(NT, GEOBI_FUSED_ARGS);
+    case 6412: return launch_nt<64, 1, 12>(NT, GEOBI_FUSED_ARGS);
+    case 12800: return launch_nt<128, 1, 0>(NT, GEOBI_FUSED_ARGS);
+    case 12806: return launch_nt<128, 1, 6>(NT, GEOBI_FUSED_ARGS);
+    case 12812: return launch_nt<128, 1, 12>(NT, GEOBI_FUSED_ARGS);
     default: return set_error("feast fused dx: unsupported Cout=%d (per-edge logit channels %d)", Cout, LC);
   }
 }

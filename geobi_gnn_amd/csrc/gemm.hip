@@ -458,6 +458,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, int I, int J, TnOutput o) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr && blockIdx.x == gridDim.x - 1) {
+    // one extra block: bias.grad[c] = sum_h (ones row)[h Cout + c].  The 9 Cout ones-row sums are formed by all 256
+    // threads (one plain slab sum each, like every other output), then folded per channel in head order.
+    __shared__ float ones_sum[GEOBI_H * 128];
+    const int HCo = GEOBI_H * o.Cout;
+    const float* base = slabs + (size_t)(I - 1) * J;
+    for (int j = threadIdx.x; j < HCo; j += blockDim.x) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < slices; ++k) t += base[(size_t)k * I * J + j];
+      ones_sum[j] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < o.Cout; c += blockDim.x) {
+      float t = 0.f;
+      for (int h = 0; h < GEOBI_H; ++h) t += ones_sum[h * o.Cout + c];
+      o.C2[c] = o.accumulate ? o.C2[c] + t : t;
+    }
+    return;
+  }
   if (idx >= I * J) return;
   float s = 0.f;
 #pragma unroll 8
@@ -478,6 +498,20 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int slices, in
       int h = i / o.Cin, k = i % o.Cin;
       if (h < GEOBI_H) dst = o.C + ((size_t)h * o.Cout + j) * o.Cin + k;
     }
+  } else if (o.mode == TN_RPRIME) {
+    // rows: input channels (+ an implicit ones row when extra_row), columns: r' = [r (9 Cout) | dp 9 + 3 | dcs 9 + 3]
+    //   data row i, j < 9 Cout            -> lin.weight.grad[j, col0 + i]        (j = h Cout + o)
+    //   data row i, 9 Cout <= j < +9      -> u.weight.grad[j - 9 Cout, col0 + i]
+    //   ones row,   j in the dcs columns  -> c.grad[h]
+    //   ones row,   j < Cout              -> bias.grad[j] = sum_h (ones row)[h Cout + j]   (sum_h sum_j q_ijh / deg_i = 1)
+    const int HC = GEOBI_H * o.Cout;
+    const bool ones = o.extra_row && i == I - 1;
+    if (!ones) {
+      if (j < HC) dst = o.C + ((size_t)j * o.Cin + o.col0 + i);
+      else if (j < HC + GEOBI_H && o.C3 != nullptr) dst = o.C3 + ((size_t)(j - HC) * o.Cin + o.col0 + i);
+    } else if (j >= HC + GEOBI_HP && j < HC + GEOBI_HP + GEOBI_H) {
+      if (o.C4 != nullptr) dst = o.C4 + (j - HC - GEOBI_HP);
+    }          // bias.grad: the extra block above
   } else {
     // TN_DU_DC: A = [dp (rows 0..8) | pad | dcs (rows 12..20) | pad], B = [x | 1]
     //   du[h, col0 + j] = row h, j < J-1 ;   dc[h] = row 12+h, j == J-1
@@ -708,7 +742,9 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   }
 #undef GEOBI_TN
   GEOBI_LAUNCH_OK();
-  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256), 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
+  const int bias_block = (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr) ? 1 : 0;
+  GEOBI_REQUIRE(!bias_block || o.Cout <= 128, "gemm_tn: bias fold holds up to 128 output channels");
+  tn_reduce_kernel<<<cdiv((int64_t)I * J, 256) + bias_block, 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
   GEOBI_LAUNCH_OK();
   prof_end(PROF_GEMM, s);
   return 0;

@@ -122,9 +122,10 @@ class DualGNN(nn.Module):
         return verts, normals, tape
 
 
-# GEOBI_DEFER_JOIN=1: join the weight-gradient side stream once per backward instead of once per layer
-# (experimental; measured neutral-to-slower on the bench workload)
-_DEFER_JOIN = os.environ.get('GEOBI_DEFER_JOIN', '0') == '1'
+# The weight-gradient GEMM of a layer ([x | 1]^T r') depends on the LAST kernel of that layer's backward, so it only
+# overlaps with anything if the side stream is joined once per backward of the whole network (the buffers it reads
+# are parked in ops._SIDE_KEEP until then) instead of once per layer.  GEOBI_DEFER_JOIN=0 restores per-layer joins.
+_DEFER_JOIN = os.environ.get('GEOBI_DEFER_JOIN', '1') == '1'
 
 
 class DualGNNFn(torch.autograd.Function):
