@@ -374,6 +374,7 @@ __global__ void feast_dp_gather_kernel(const int* __restrict__ rowptr_out, const
   if (n >= N) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   int rs = rowptr_out[n], re = rowptr_out[n + 1];
+#pragma unroll 4
   for (int e = rs; e < re; ++e) {
     float4 v = reinterpret_cast<const float4*>(dl + (size_t)pos_in[e] * HP)[q];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
