@@ -1,0 +1,113 @@
+"""The pieces of the reference's training loop that touch the hot path's parameters and outputs, behind the same
+flag names (/root/reference/code/train_dual.py:39-96 flags, :162-180 optimisers and
+learning-rate schedules, :233-263 evaluation means, :270-276 best-on-eval checkpoint).
+
+The loop itself (data loading, TensorBoard, progress bars) is the reference's Python harness and stays out of
+scope; tools/train_synthetic.py drives these helpers on synthetic meshes.
+"""
+import math
+
+import torch
+from torch.optim import lr_scheduler
+
+from . import network
+from .parallel import reduce_sums
+
+LR_SCHEDULES = ('step', 'multi_step', 'exp', 'auto', 'lmd')
+
+
+def add_training_flags(parser):
+    """The optimiser / schedule / loss flags of train_dual.py:57-82, same names, types and defaults."""
+    parser.add_argument('--loss_v', type=str, default='L1')
+    parser.add_argument('--loss_n', type=str, default='L1')
+    parser.add_argument('--loss_v_scale', type=float, default=1)
+    parser.add_argument('--loss_n_scale', type=float, default=1)
+    parser.add_argument('--wei_param', type=int, default=2)
+    parser.add_argument('--max_epoch', type=int, default=1000)
+    parser.add_argument('--batch_size', type=int, default=1)
+    parser.add_argument('--lr_sch', type=str, default='lmd')
+    parser.add_argument('--lr', type=float, default=0.001)
+    parser.add_argument('--lr_step', type=int, nargs='+', default=[10])
+    parser.add_argument('--lr_decay', type=float, default=1)
+    parser.add_argument('--optimizer', type=str, default='adam')
+    parser.add_argument('--momentum', type=float, default=0.9)
+    parser.add_argument('--beta1', type=float, default=0.9)
+    parser.add_argument('--beta2', type=float, default=0.999)
+    parser.add_argument('--weight_decay', type=float, default=0)
+    return parser
+
+
+def make_optimizer(opt, params, fused=None):
+    """train_dual.py:162-167.  `fused`: single-kernel Adam over the flat parameter (same update rule)."""
+    if opt.optimizer == 'sgd':
+        return torch.optim.SGD(params, lr=opt.lr, momentum=opt.momentum, weight_decay=opt.weight_decay)
+    if opt.optimizer == 'rmsprop':
+        return torch.optim.RMSprop(params, lr=opt.lr, alpha=0.9)
+    if opt.optimizer == 'adam':
+        kw = {} if fused is None else {'fused': bool(fused)}
+        return torch.optim.Adam(params, lr=opt.lr, betas=(opt.beta1, opt.beta2), weight_decay=opt.weight_decay, **kw)
+    raise ValueError('optimizer %r: the reference knows sgd, rmsprop and adam' % (opt.optimizer,))
+
+
+def make_scheduler(opt, optimizer):
+    """train_dual.py:169-180: 'step', 'multi_step', 'exp', 'auto' (reduce on plateau of the evaluation normal
+    error), anything else = the exponential lambda rule lr * decay^(epoch / lr_step[0])."""
+    steps = list(opt.lr_step) if isinstance(opt.lr_step, (list, tuple)) else [opt.lr_step]
+    if opt.lr_sch == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=steps[0], gamma=opt.lr_decay)
+    if opt.lr_sch == 'multi_step':
+        return lr_scheduler.MultiStepLR(optimizer, milestones=steps, gamma=opt.lr_decay)
+    if opt.lr_sch == 'exp':
+        return lr_scheduler.ExponentialLR(optimizer, gamma=opt.lr_decay)
+    if opt.lr_sch == 'auto':
+        return lr_scheduler.ReduceLROnPlateau(optimizer, factor=opt.lr_decay, patience=steps[0])
+    return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: opt.lr_decay ** (epoch / steps[0]))
+
+
+def step_scheduler(opt, sch, eval_error_f):
+    """train_dual.py:261-264: the plateau schedule watches the evaluation normal error."""
+    if opt.lr_sch == 'auto':
+        sch.step(eval_error_f)
+    else:
+        sch.step()
+
+
+class EvalMeter(object):
+    """Node-count-weighted means of the evaluation pass (train_dual.py:233-259): losses and errors of each mesh
+    weighted by its vertex / face count, summed -- across ranks too (six scalars, one all-reduce) -- then divided."""
+
+    def __init__(self):
+        self.sums = [0.0] * 6         # loss_v * nv, loss_f * nf, error_v * nv, error_f * nf, nv, nf
+
+    def add(self, loss_v, loss_f, error_v, error_f, num_v, num_f):
+        for i, v in enumerate((float(loss_v) * num_v, float(loss_f) * num_f, float(error_v) * num_v,
+                               float(error_f) * num_f, num_v, num_f)):
+            self.sums[i] += v
+
+    def add_prediction(self, vert_p, norm_p, data_v, data_f, loss_v='L1', loss_n='L1'):
+        self.add(network.loss_v(vert_p, data_v.y, loss_v), network.loss_n(norm_p, data_f.y, loss_n),
+                 network.error_v(vert_p, data_v.y), network.error_n(norm_p, data_f.y),
+                 data_v.y.shape[0], data_f.y.shape[0])
+
+    def result(self, device=None):
+        """dict(eval_loss_v, eval_loss_f, eval_error_v, eval_error_f); reduced over the process group if there is one."""
+        s = self.sums if device is None else reduce_sums(self.sums, device)
+        cv, cf = max(s[4], 1.0), max(s[5], 1.0)
+        return {'eval_loss_v': s[0] / cv, 'eval_loss_f': s[1] / cf, 'eval_error_v': s[2] / cv, 'eval_error_f': s[3] / cf}
+
+
+class BestCheckpoint(object):
+    """train_dual.py:270-276: keep the state dict with the lowest evaluation normal error.  Keys are the module's own
+    (= the reference's: gnn_v.l_conv1.lin.weight ... fc_f2.bias), values plain tensors that
+    torch.load(weights_only=True) and the reference's net.load_state_dict(torch.load(path)) both read."""
+
+    def __init__(self, path):
+        self.path, self.best = path, math.inf
+
+    def update(self, net, eval_error_f):
+        if not (eval_error_f < self.best):
+            return False
+        self.best = float(eval_error_f)
+        if self.path:
+            torch.save({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, self.path)
+        return True

@@ -400,3 +400,90 @@ def test_bench_relays_a_failing_child_and_checks_world_size():
     # launched by an outer torchrun with a different world size: refused, not silently mis-reported
     r = _run_bench('--gpus', '2', '--steps', '1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     assert r.returncode != 0 and 'WORLD_SIZE=1 but --gpus 2' in r.stderr
+
+
+def _opt(**kw):
+    import argparse
+    from geobi_gnn_amd import train_util
+    base = train_util.add_training_flags(argparse.ArgumentParser()).parse_args([])
+    for k, v in kw.items():
+        setattr(base, k, v)
+    return base
+
+
+def test_training_flags_match_the_reference_defaults():
+    """same flag names and defaults as train_dual.py:57-82."""
+    o = _opt()
+    assert (o.loss_v, o.loss_n, o.loss_v_scale, o.loss_n_scale, o.wei_param) == ('L1', 'L1', 1, 1, 2)
+    assert (o.max_epoch, o.batch_size, o.lr_sch, o.lr, o.lr_step, o.lr_decay) == (1000, 1, 'lmd', 0.001, [10], 1)
+    assert (o.optimizer, o.momentum, o.beta1, o.beta2, o.weight_decay) == ('adam', 0.9, 0.9, 0.999, 0)
+
+
+@pytest.mark.parametrize('name', ['step', 'multi_step', 'exp', 'auto', 'lmd'])
+def test_lr_schedules_reproduce_the_reference_step_for_step(name):
+    """The five schedules of train_dual.py:169-180, epoch by epoch, against the constructors written out as the
+    reference writes them (incl. the plateau schedule stepping on the evaluation normal error, :261-264)."""
+    from torch.optim import lr_scheduler
+    from geobi_gnn_amd import train_util
+    opt = _opt(lr_sch=name, lr=0.01, lr_decay=0.7, lr_step=[3, 7, 12] if name == 'multi_step' else [3])
+    w = [torch.nn.Parameter(torch.ones(3)) for _ in range(2)]
+    ours_opt, ref_opt = torch.optim.Adam([w[0]], lr=opt.lr), torch.optim.Adam([w[1]], lr=opt.lr)
+    ours = train_util.make_scheduler(opt, ours_opt)
+    if name == 'step':
+        ref = lr_scheduler.StepLR(ref_opt, step_size=opt.lr_step[0], gamma=opt.lr_decay)
+    elif name == 'multi_step':
+        ref = lr_scheduler.MultiStepLR(ref_opt, milestones=opt.lr_step, gamma=opt.lr_decay)
+    elif name == 'exp':
+        ref = lr_scheduler.ExponentialLR(ref_opt, gamma=opt.lr_decay)
+    elif name == 'auto':
+        ref = lr_scheduler.ReduceLROnPlateau(ref_opt, factor=opt.lr_decay, patience=opt.lr_step[0])
+    else:
+        ref = lr_scheduler.LambdaLR(ref_opt, lr_lambda=lambda step: opt.lr_decay ** (step / opt.lr_step[0]))
+    metric = [5.0, 4.0, 4.1, 4.2, 4.3, 4.4, 4.5, 3.0, 3.1, 3.2, 3.3, 3.4, 3.5, 3.6, 3.7, 3.8, 2.0, 2.1, 2.2, 2.3]
+    seen = []
+    for epoch in range(20):
+        ours_opt.step(); ref_opt.step()
+        train_util.step_scheduler(opt, ours, metric[epoch])
+        if name == 'auto':
+            ref.step(metric[epoch])
+        else:
+            ref.step()
+        assert ours_opt.param_groups[0]['lr'] == ref_opt.param_groups[0]['lr'], (name, epoch)
+        seen.append(ours_opt.param_groups[0]['lr'])
+    assert len(set(seen)) > 2                       # the schedule actually moved the rate
+
+
+def test_optimizers_eval_means_and_checkpoint_keys(tmp_path):
+    """train_dual.py:162-167 optimiser settings, :246-259 node-count-weighted evaluation means, :270-276 best
+    checkpoint -- whose file the reference's `net.load_state_dict(torch.load(path))` must accept (checked against
+    the oracle's restatement of the reference module tree, strict key match)."""
+    from geobi_gnn_amd import network, train_util
+    from oracle import ref_model as R
+    p = [torch.nn.Parameter(torch.ones(2))]
+    a = train_util.make_optimizer(_opt(optimizer='adam', beta1=0.8, beta2=0.95, weight_decay=0.01), p)
+    assert isinstance(a, torch.optim.Adam) and a.defaults['betas'] == (0.8, 0.95) and a.defaults['weight_decay'] == 0.01
+    s = train_util.make_optimizer(_opt(optimizer='sgd', momentum=0.7), p)
+    assert isinstance(s, torch.optim.SGD) and s.defaults['momentum'] == 0.7
+    r = train_util.make_optimizer(_opt(optimizer='rmsprop'), p)
+    assert isinstance(r, torch.optim.RMSprop) and r.defaults['alpha'] == 0.9
+    with pytest.raises(ValueError):
+        train_util.make_optimizer(_opt(optimizer='lbfgs'), p)
+
+    meter = train_util.EvalMeter()
+    rows = [(0.5, 0.2, 0.05, 3.0, 100, 196), (0.3, 0.1, 0.02, 1.0, 1000, 1996), (0.9, 0.4, 0.09, 7.5, 10, 16)]
+    lv = lf = ev = ef = cv = cf = 0.0
+    for l_v, l_f, e_v, e_f, nv, nf in rows:
+        meter.add(l_v, l_f, e_v, e_f, nv, nf)
+        lv += l_v * nv; lf += l_f * nf; ev += e_v * nv; ef += e_f * nf; cv += nv; cf += nf     # :246-251
+    res = meter.result()
+    assert res == {'eval_loss_v': lv / cv, 'eval_loss_f': lf / cf, 'eval_error_v': ev / cv, 'eval_error_f': ef / cf}
+
+    net = network.DualGNN()
+    path = str(tmp_path / 'best.pt')
+    ck = train_util.BestCheckpoint(path)
+    assert ck.update(net, 3.0) and not ck.update(net, 3.5) and ck.update(net, 2.5) and ck.best == 2.5
+    sd = torch.load(path, map_location='cpu', weights_only=True)
+    ora = R.DualGNN()
+    assert list(sd.keys()) == list(ora.state_dict().keys())
+    ora.load_state_dict(sd, strict=True)
+    assert torch.equal(ora.fc_f2.weight, net.fc_f2.weight.detach())

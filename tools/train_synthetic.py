@@ -2,7 +2,7 @@
 
 Same loop structure and flag names for the parts that touch the hot path -- gradient accumulation
 over ``--batch_size`` meshes (here: one disjoint-union step), L1/L2 losses with scales, Adam / SGD /
-RMSprop, step / exp / lambda LR schedules, per-epoch evaluation with node-count-weighted means
+RMSprop, the five LR schedules (step / multi_step / exp / auto / lambda), per-epoch evaluation with node-count-weighted means
 (train_dual.py:233-263), best-on-eval checkpoint with the reference's state-dict keys.  The datasets
 of the reference are external downloads, so meshes are noisy icospheres (meshgen.py).  Data parallel:
 launch through ``python -m torch.distributed.run --nproc-per-node N tools/train_synthetic.py ...``;
@@ -20,37 +20,26 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from geobi_gnn_amd import network, meshgen          # noqa: E402
+from geobi_gnn_amd import network, meshgen, train_util          # noqa: E402
 from geobi_gnn_amd.data import union_batch_graphs, RandomRotate   # noqa: E402
-from geobi_gnn_amd.parallel import (init_distributed, FlatParameters, shard_indices, batched_losses,   # noqa: E402
-                                    reduce_sums)
+from geobi_gnn_amd.parallel import init_distributed, FlatParameters, shard_indices, batched_losses   # noqa: E402
 
 
-def parse_arguments():
+def parse_arguments(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--freq', type=int, default=16, help='icosphere frequency (F = 20 freq^2)')
     p.add_argument('--n_train', type=int, default=12)
     p.add_argument('--n_eval', type=int, default=4)
-    p.add_argument('--loss_v', type=str, default='L1')
-    p.add_argument('--loss_n', type=str, default='L1')
-    p.add_argument('--loss_v_scale', type=float, default=1)
-    p.add_argument('--loss_n_scale', type=float, default=1)
-    p.add_argument('--wei_param', type=int, default=2)
-    p.add_argument('--max_epoch', type=int, default=10)
-    p.add_argument('--batch_size', type=int, default=4)
-    p.add_argument('--lr', type=float, default=1e-3)
-    p.add_argument('--lr_sch', type=str, default='lmd', choices=['lmd', 'step', 'exp', 'none'])
-    p.add_argument('--lr_step', type=int, default=50)
-    p.add_argument('--lr_decay', type=float, default=0.5)
-    p.add_argument('--optimizer', type=str, default='adam', choices=['adam', 'sgd', 'rmsprop'])
+    train_util.add_training_flags(p)                  # the reference's flag names (train_dual.py:57-82)
+    p.set_defaults(max_epoch=10, batch_size=4)
     p.add_argument('--rotate', type=int, default=0, help='1: random z rotation per batch, 2: full 3-axis (dataset.py:39-69)')
     p.add_argument('--seed', type=int, default=40938661)
     p.add_argument('--out', type=str, default='')
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def main():
-    opt = parse_arguments()
+def main(argv=None):
+    opt = parse_arguments(argv)
     rank, world, device = init_distributed()
     assert torch.cuda.is_available(), 'the geobi path runs on the MI355X only'
     torch.manual_seed(opt.seed)
@@ -65,21 +54,9 @@ def main():
 
     net = network.DualGNN(force_depth=False, pool_type='max', wei_param=opt.wei_param).to(device)
     flat = FlatParameters(net)
-    params = flat.parameters()
-    if opt.optimizer == 'adam':
-        optimizer = torch.optim.Adam(params, lr=opt.lr, fused=True)
-    elif opt.optimizer == 'sgd':
-        optimizer = torch.optim.SGD(params, lr=opt.lr, momentum=0.9)
-    else:
-        optimizer = torch.optim.RMSprop(params, lr=opt.lr)
-    if opt.lr_sch == 'step':
-        sch = torch.optim.lr_scheduler.StepLR(optimizer, opt.lr_step, opt.lr_decay)
-    elif opt.lr_sch == 'exp':
-        sch = torch.optim.lr_scheduler.ExponentialLR(optimizer, 0.99)
-    elif opt.lr_sch == 'lmd':
-        sch = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda e: max(0.0, 1 - e / float(opt.max_epoch)) * 0.9 + 0.1)
-    else:
-        sch = None
+    optimizer = train_util.make_optimizer(opt, flat.parameters(), fused=True if opt.optimizer == 'adam' else None)
+    sch = train_util.make_scheduler(opt, optimizer)
+    ckpt = train_util.BestCheckpoint(opt.out if rank == 0 else '')
 
     import numpy as np
     rotate = None if not opt.rotate else RandomRotate(z_rotated=opt.rotate == 1, rng=np.random.default_rng(opt.seed + rank))
@@ -99,31 +76,23 @@ def main():
             loss.backward()
             flat.bucket.all_reduce_mean()
             optimizer.step()
-        # evaluation: node-count-weighted means over the eval meshes of every rank
+        # evaluation: node-count-weighted means over the eval meshes of every rank (train_dual.py:233-259)
         net.eval()
-        sums = [0.0] * 6
+        meter = train_util.EvalMeter()
         with torch.no_grad():
             for a, b in evals[rank::world]:
                 vp, npred, _ = net((a.shallow_copy(), b.shallow_copy()))
-                nv, nf = a.y.shape[0], b.y.shape[0]
-                sums[0] += float(network.loss_v(vp, a.y, opt.loss_v)) * nv
-                sums[1] += float(network.loss_n(npred, b.y, opt.loss_n)) * nf
-                sums[2] += float(network.error_v(vp, a.y)) * nv
-                sums[3] += float(network.error_n(npred, b.y)) * nf
-                sums[4] += nv
-                sums[5] += nf
-        sums = reduce_sums(sums, device)
-        rec = {'epoch': epoch, 'train_loss': float(loss.detach()), 'eval_loss_v': sums[0] / sums[4], 'eval_loss_f': sums[1] / sums[5],
-               'eval_error_v': sums[2] / sums[4], 'eval_error_f_deg': sums[3] / sums[5],
-               'lr': optimizer.param_groups[0]['lr'], 'epoch_s': round(time.time() - t0, 3)}
+                meter.add_prediction(vp, npred, a, b, opt.loss_v, opt.loss_n)
+        res = meter.result(device)
+        rec = {'epoch': epoch, 'train_loss': float(loss.detach()), 'eval_loss_v': res['eval_loss_v'],
+               'eval_loss_f': res['eval_loss_f'], 'eval_error_v': res['eval_error_v'],
+               'eval_error_f_deg': res['eval_error_f'], 'lr': optimizer.param_groups[0]['lr'],
+               'epoch_s': round(time.time() - t0, 3)}
         history.append(rec)
+        saved = ckpt.update(net, rec['eval_error_f_deg'])     # keys: gnn_v.l_conv1.lin.weight ... fc_f2.bias
         if rank == 0:
-            print(json.dumps(rec), flush=True)
-            if rec['eval_error_f_deg'] < best and opt.out:
-                best = rec['eval_error_f_deg']
-                torch.save(net.state_dict(), opt.out)       # keys: gnn_v.l_conv1.lin.weight ... fc_f2.bias
-        if sch is not None:
-            sch.step()
+            print(json.dumps(dict(rec, saved=saved)), flush=True)
+        train_util.step_scheduler(opt, sch, rec['eval_error_f_deg'])
     return history
 
 
