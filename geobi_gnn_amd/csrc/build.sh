@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
 OBJS=()
 mkdir -p "$HERE/build"
-for f in capi graph gemm feast feast_fused pool geom head_fused meshprep patch; do
+for f in capi executor graph gemm feast feast_fused pool geom head_fused meshprep patch; do
   src="$HERE/$f.hip"; obj="$HERE/build/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/geobi_hip.h" -nt "$obj" ]; then
     echo "hipcc $f.hip"

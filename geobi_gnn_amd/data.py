@@ -169,6 +169,12 @@ def union_batch_graphs(dual_list):
                   fv_indices=torch.cat(fv), name='union-f')
     data_v.set_graph(Graph.union(gvs))
     data_f.set_graph(Graph.union(gfs))
+    parts = [getattr(df.fv_indices, '_geobi_fv', None) for _, df in dual_list]
+    if all(p is not None and p[2] == dv.x.shape[0] for p, (dv, _) in zip(parts, dual_list)):
+        # every part's face table is already validated: so is the union (no range check = no host read later)
+        from .network import mark_face_table
+        fv32 = torch.cat([p[0] + off for p, off in zip(parts, ptr_v[:-1])])
+        mark_face_table(data_f.fv_indices, fv32, ptr_v[-1])
     data_v.edge_weight = torch.cat([g.weights_sorted(dv.edge_weight) for g, (dv, _) in zip(gvs, dual_list)])
     data_f.edge_weight = torch.cat([g.weights_sorted(df.edge_weight) for g, (_, df) in zip(gfs, dual_list)])
     data_v.mesh_ptr = torch.tensor(ptr_v, dtype=torch.long)

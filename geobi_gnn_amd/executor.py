@@ -1,0 +1,172 @@
+"""Binding of the whole-network forward (geobi_net_forward, include/geobi_hip.h): DualGNN's inference pass as one
+library call.  The module-by-module path of network.py stays the reference for it (same kernels, same order,
+bit-identical outputs) and takes over whenever a case is outside the fast path.
+
+GEOBI_NET_EXECUTOR=0 turns it off (A/B timing; the parity tests run both)."""
+import ctypes
+import os
+
+import torch
+
+from . import _lib as L
+
+ENABLED = os.environ.get('GEOBI_NET_EXECUTOR', '1') == '1'
+STATS = {'calls': 0, 'fallback': 0, 'arena_retry': 0}      # how often the fast path was taken / left
+
+_F = ctypes.c_void_p
+
+
+class _Conv(ctypes.Structure):
+    _fields_ = [('lin_w', _F), ('u_w', _F), ('c', _F), ('bias', _F)]
+
+
+class _Gnn(ctypes.Structure):
+    _fields_ = [('conv', _Conv * 8)]
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [('gnn_v', _Gnn), ('gnn_f', _Gnn),
+                ('fc_v1_w', _F), ('fc_v1_b', _F), ('fc_v2_w', _F), ('fc_v2_b', _F),
+                ('fc_f1_w', _F), ('fc_f1_b', _F), ('fc_f2_w', _F), ('fc_f2_b', _F),
+                ('force_depth', ctypes.c_int32), ('pool_mean', ctypes.c_int32)]
+
+
+class _Level0(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int64), ('E', ctypes.c_int64), ('rowptr', _F), ('col', _F), ('row', _F), ('weight', _F)]
+
+
+class _Branch(ctypes.Structure):
+    _fields_ = [('nodes', ctypes.c_int64 * 3), ('unpool_off', ctypes.c_int64 * 2),
+                ('cluster_off', (ctypes.c_int64 * 2) * 2), ('cluster_len', (ctypes.c_int64 * 2) * 2)]
+
+
+class _Out(ctypes.Structure):
+    _fields_ = [('verts_off', ctypes.c_int64), ('normals_off', ctypes.c_int64), ('xf_off', ctypes.c_int64),
+                ('used_bytes', ctypes.c_int64), ('v', _Branch), ('f', _Branch)]
+
+
+_CONVS = ('l_conv1', 'l_conv2', 'l_conv3', 'l_conv4', 'r_conv1', 'r_conv2', 'r_conv3', 'r_conv4')
+
+
+def _f32(t, what):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise L.GeobiError('%s: expected a float32 tensor on the device' % what)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _pack_params(net):
+    """(struct, tensors kept alive).  72 pointers; rebuilt per call (~10 us) so .to() / load_state_dict stay safe."""
+    p, keep = _Params(), []
+
+    def ptr(t, what):
+        t = _f32(t.detach(), what)
+        keep.append(t)
+        return t.data_ptr()
+    for gname in ('gnn_v', 'gnn_f'):
+        g, mod = getattr(p, gname), getattr(net, gname)
+        for i, cname in enumerate(_CONVS):
+            c = getattr(mod, cname)
+            g.conv[i].lin_w, g.conv[i].u_w = ptr(c.lin.weight, cname), ptr(c.u.weight, cname)
+            g.conv[i].c, g.conv[i].bias = ptr(c.c, cname), ptr(c.bias, cname)
+    for fc in ('fc_v1', 'fc_v2', 'fc_f1', 'fc_f2'):
+        m = getattr(net, fc)
+        setattr(p, fc + '_w', ptr(m.weight, fc))
+        setattr(p, fc + '_b', ptr(m.bias, fc))
+    p.force_depth = 1 if net.force_depth else 0
+    p.pool_mean = 1 if net.gnn_v.pooling1.pool_type == 'mean' else 0
+    return p, keep
+
+
+def supported(net):
+    """The fast path covers the network as the reference builds it (edge_weight_type 10, two matching steps, no
+    injected cluster vectors); everything else runs module by module."""
+    for g in (net.gnn_v, net.gnn_f):
+        for pl in (g.pooling1, g.pooling2):
+            if pl.edge_weight_type != 10 or pl.pool_step != 2 or pl.graclus_fn is not None:
+                return False
+    return net.gnn_v.pooling1.pool_type == net.gnn_f.pooling1.pool_type
+
+
+def _level0(data, keep):
+    g = data.graph(data.x.shape[0])
+    if not g.symmetric or g.E == 0:
+        return None
+    w = getattr(data, 'edge_weight', None)
+    if w is None:
+        return None
+    w = _f32(g.weights_sorted(w), 'edge_weight')
+    row = g.ensure_rows()
+    keep += [g, w, row]
+    lv = _Level0()
+    lv.N, lv.E = g.N, g.E
+    lv.rowptr, lv.col, lv.row, lv.weight = g.rowptr_out.data_ptr(), g.col_out.data_ptr(), row.data_ptr(), w.data_ptr()
+    return lv
+
+
+# One grow-only arena per device, reused by every call: a fresh ~0.5 GB block per pass costs a device allocation
+# whenever the batch shape changes (patch unions of different sizes).  Results are therefore COPIED out (two small
+# tensors); what the pooling modules expose afterwards (unpool index, cluster vectors) stays in the arena and, like
+# any module state of "the last forward", is valid until the next one.
+_ARENAS = {}
+
+
+def _arena(nbytes, dev):
+    key = (dev.type, dev.index)
+    a = _ARENAS.get(key)
+    if a is None or a.numel() < nbytes:
+        _ARENAS[key] = a = None                      # release before growing
+        _ARENAS[key] = a = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+    return a
+
+
+def _views(arena, off, n, dtype):
+    nbytes = n * 4
+    return arena[off:off + nbytes].view(dtype)
+
+
+def forward(net, data_v, data_f):
+    """-> (verts [V,3], normals [F,3]) or None (not covered: the caller runs the module-by-module path).  Sets the
+    module-surface side effects of a forward that callers read: PoolingLayer.unpooling_indices / last_clusters."""
+    from .network import _fv_index
+    if not (ENABLED and supported(net)):
+        return None
+    keep = []
+    lv_v, lv_f = _level0(data_v, keep), _level0(data_f, keep)
+    if lv_v is None or lv_f is None or data_v.x.shape[1] != 6 or data_f.x.shape[1] != 6:
+        return None
+    dev = data_v.x.device
+    x_v, x_f = _f32(data_v.x, 'data_v.x'), _f32(data_f.x, 'data_f.x')
+    fv32, _ = _fv_index(data_f, x_v.shape[0])
+    dd = None
+    if net.force_depth:
+        dd = _f32(data_v.depth_direction, 'depth_direction')
+    prm, pkeep = _pack_params(net)
+    lib = L.lib()
+    nbytes = L.size_query('geobi_net_forward_arena_bytes', lv_v.N, lv_v.E, lv_f.N, lv_f.E)
+    out = _Out()
+    for _ in range(2):
+        arena = _arena(nbytes, dev)
+        rc = lib.geobi_net_forward(ctypes.byref(prm), ctypes.byref(lv_v), ctypes.byref(lv_f), x_v.data_ptr(),
+                                   x_f.data_ptr(), fv32.data_ptr(), None if dd is None else dd.data_ptr(),
+                                   arena.data_ptr(), arena.numel(), ctypes.byref(out), L.stream())
+        if rc != 3:                                   # GEOBI_NET_ARENA: retry once with twice what was needed
+            break
+        nbytes = max(2 * int(out.used_bytes), 2 * nbytes)
+        STATS['arena_retry'] += 1
+    STATS['calls'] += 1
+    if rc == 2:                                       # GEOBI_NET_FALLBACK
+        STATS['fallback'] += 1
+        return None
+    if rc != 0:
+        L.check(rc, 'geobi_net_forward')
+    V, F = lv_v.N, lv_f.N
+    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
+    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
+    for gname, bo in (('gnn_v', out.v), ('gnn_f', out.f)):
+        mod = getattr(net, gname)
+        for l, pl in enumerate((mod.pooling1, mod.pooling2)):
+            pl._unpool32 = _views(arena, bo.unpool_off[l], bo.nodes[l], torch.int32)
+            pl._unpool64 = None
+            pl._unpool_index = None                  # inverse lists are a training-time structure
+            pl._last_clusters32 = [_views(arena, bo.cluster_off[l][t], bo.cluster_len[l][t], torch.int32) for t in range(2)]
+    return verts, normals

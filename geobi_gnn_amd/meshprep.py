@@ -155,6 +155,8 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
 
     data_v = Data(torch.cat(((pts - cen) * sc, vn), 1), None, name=name + '-v')
     data_f = Data(torch.cat(((pos_f - cen) * sc, fn), 1), None, fv_indices=fv.long(), name=name + '-f')
+    from .network import mark_face_table
+    mark_face_table(data_f.fv_indices, fv, V)          # ids were range-checked above
     if reference_layout:
         ei_v, w_v = _reference_coo(g_v, ew_v, vn, loops_inline=False)
         ei_f, w_f = _reference_coo(g_f, ew_f, fn, loops_inline=True)

@@ -143,7 +143,69 @@ class _CounterPool(object):
         return q
 
 
+    def take_block(self, k, device):
+        """k consecutive zeroed quads as one [k, 4] tensor (one read-back serves all of them)."""
+        key = (device.type, device.index)
+        if self.buf is None or self.key != key or self.used + k > self.buf.shape[0]:
+            self.buf, self.used, self.key = torch.zeros((256, 4), dtype=torch.int32, device=device), 0, key
+        q = self.buf[self.used:self.used + k]
+        self.used += k
+        return q
+
+
 _counters = _CounterPool()
+
+# GEOBI_CHAIN_POOL=0: one size read-back per matching step (round-1 behaviour) instead of one per pooling layer
+_CHAIN = os.environ.get('GEOBI_CHAIN_POOL', '1') == '1'
+
+
+def _coarsen_chain(g0, w0, steps, rounds=MATCH_ROUNDS):
+    """All `steps` matching steps of a pooling layer back to back, ONE host read at the end.
+
+    Only the first step of a layer depends on features (through the edge weights it is handed); the later
+    ones run on the pooled weights.  So the integer pipeline  match -> relabel -> lists -> pool_edge  of every
+    step is enqueued without knowing the sizes of the previous one: step s + 1 runs on the coarse graph PADDED to
+    the fine node count P -- rows past the true count are empty, i.e. isolated nodes that the matching closes as
+    singletons with ids above every real cluster -- and the device-side counters of all steps come back in one
+    copy.  Everything handed on is then cut to its exact size; nothing padded leaves this function, and the
+    result is what the step-by-step path gives (the padding nodes never touch a real node's proposals).
+
+    Returns None when a step overflowed the sort-free edge coarsening or did not converge in `rounds` rounds
+    (the caller then takes the step-by-step path), else (clusts, raw, sidxs, coarse graph, coarse weights)."""
+    P, dev = g0.N, g0.device
+    ctr = _counters.take_block(steps, dev)
+    g, w, outs = g0, w0, []
+    for s in range(steps):
+        cluster32, cnew, sidx, _ = hip_match_coarsen(g, w, ctr[s], rounds)
+        rowptr_c, row_c, col_c, w_c = _pool_edge_rows(cnew, sidx, g, w, ctr[s][1:2], ctr[s][2:3], ctr[s][3:4])
+        outs.append((cluster32, cnew, sidx, rowptr_c, row_c, col_c, w_c))
+        if s + 1 < steps:
+            g = Graph.from_sorted(P, rowptr_c, row_c, col_c, symmetric=g0.symmetric)     # padded to P rows
+            w = w_c
+    vals = L.read_i32(ctr, 4 * steps)
+    real = [P]                                   # true node count per level
+    edges = []
+    for s in range(steps):
+        undecided, nc_total, ec, overflow = vals[4 * s:4 * s + 4]
+        if undecided or overflow:
+            return None
+        real.append(nc_total - (P - real[-1]))   # the padding nodes of the input came back as singletons
+        edges.append(ec)
+        if ec == 0:                              # the reference stops pooling once no edge is left (net_util.py:139)
+            break
+    clusts, raw, sidxs = [], [], []
+    for s in range(len(edges)):
+        cluster32, cnew, sidx, rowptr_c, row_c, col_c, w_c = outs[s]
+        n_in, n_out = real[s], real[s + 1]
+        exact = ops.SegmentIndex.view(cnew[:n_in], n_out, sidx.segptr[:n_out + 1], sidx.members[:n_in])
+        clusts.append(exact.seg)
+        raw.append(cluster32[:n_in])
+        sidxs.append(exact)
+    last = len(edges) - 1
+    _, _, _, rowptr_c, row_c, col_c, w_c = outs[last]
+    nc, ec = real[last + 1], edges[last]
+    coarse = Graph.from_sorted(nc, rowptr_c[:nc + 1], row_c[:ec], col_c[:ec], symmetric=g0.symmetric)
+    return clusts, raw, sidxs, coarse, (None if w_c is None else w_c[:ec])
 
 
 def _coarsen(graph, weight_sorted, cluster32=None, rounds=MATCH_ROUNDS):
@@ -299,22 +361,33 @@ class PoolingLayer(nn.Module):
         face = getattr(data, 'fv_indices', None)
 
         clusts, raw, sidxs = [], [], []
-        for _ in range(self.pool_step):
-            given = None
-            if self.graclus_fn is not None:
-                given = _i32(self.graclus_fn(g.coo64(), edge_weight, g.N))
-            cnew, g_c, w_c, cl_raw, sidx = _coarsen(g, edge_weight, given)
-            raw.append(cl_raw)
-            clusts.append(cnew)
-            if sidx is None:
-                sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
-            sidxs.append(sidx)
-            x = _pool_features(x, sidx, self.pool_type)
-            pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
-            edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
-            g, edge_weight = g_c, w_c
-            if g.E == 0:
-                break
+        chain = None
+        if _CHAIN and self.graclus_fn is None and self.pool_step > 1 and g.E > 0 and g.N > 0:
+            chain = _coarsen_chain(g, edge_weight, self.pool_step)
+        if chain is not None:
+            # structure of every step from one read-back; the features follow with exact sizes
+            clusts, raw, sidxs, g, edge_weight = chain
+            for cnew, sidx in zip(clusts, sidxs):
+                x = _pool_features(x, sidx, self.pool_type)
+                pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
+                edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
+        else:
+            for _ in range(self.pool_step):
+                given = None
+                if self.graclus_fn is not None:
+                    given = _i32(self.graclus_fn(g.coo64(), edge_weight, g.N))
+                cnew, g_c, w_c, cl_raw, sidx = _coarsen(g, edge_weight, given)
+                raw.append(cl_raw)
+                clusts.append(cnew)
+                if sidx is None:
+                    sidx = ops.SegmentIndex.from_matching(cnew, cl_raw, g_c.N)
+                sidxs.append(sidx)
+                x = _pool_features(x, sidx, self.pool_type)
+                pos = None if pos is None else ops.apply_op(ops.SegmentMeanFn, pos, sidx)
+                edge_dual = None if edge_dual is None else cnew.long()[edge_dual]
+                g, edge_weight = g_c, w_c
+                if g.E == 0:
+                    break
 
         clust = _compose(clusts)
         self._unpool32, self._unpool64 = clust, None
@@ -330,6 +403,9 @@ class PoolingLayer(nn.Module):
     def unpooling(self, x):
         if self._unpool32 is None:
             return x
+        if self._unpool_index is None:       # forward ran through the whole-network executor: lists built on demand
+            nseg = int(self._unpool32.max().item()) + 1
+            self._unpool_index = ops.SegmentIndex(self._unpool32.contiguous(), nseg)
         return ops.apply_op(ops.UnpoolFn, x, self._unpool_index)
 
 

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from . import ops
+from . import executor, ops
 from .feast_conv import FeaStConv
 from .net_util import PoolingLayer
 
@@ -59,8 +59,27 @@ class GNNModule(nn.Module):
         return self.r_conv4(data_r1.x, g1, x2=up1, slope=LEAK)
 
 
+class _CornerIndex(object):
+    """vertex -> corner inverse lists of a face table (FaceGeomFn.backward sums corner gradients through them);
+    built on first use, so inference never pays for the sort."""
+
+    def __init__(self, fv32, num_vertices):
+        self.fv32, self.num_vertices, self.index = fv32, num_vertices, None
+
+    def get(self):
+        if self.index is None:
+            self.index = ops.SegmentIndex(self.fv32.view(-1), self.num_vertices)
+        return self.index
+
+
+def mark_face_table(fv, fv32, num_vertices):
+    """Attach the validated int32 form of a face table to it (producers that know their ids are in range -- device
+    preprocessing, unions of validated tables -- call this so the forward needs no range check, i.e. no host read)."""
+    fv._geobi_fv = (fv32, _CornerIndex(fv32, num_vertices), num_vertices)
+
+
 def _fv_index(data_f, num_vertices):
-    """int32 face->vertex table and the vertex->corner inverse lists, cached on the tensor."""
+    """int32 face->vertex table and the (lazy) vertex->corner inverse lists, cached on the tensor."""
     fv = data_f.fv_indices
     cache = getattr(fv, '_geobi_fv', None)
     if cache is None or cache[2] != num_vertices:
@@ -69,9 +88,8 @@ def _fv_index(data_f, num_vertices):
             lo, hi = torch.aminmax(fv32)
             if int(lo) < 0 or int(hi) >= num_vertices:
                 raise L.GeobiError('fv_indices index vertices outside [0, %d)' % num_vertices)
-        cidx = ops.SegmentIndex(fv32.view(-1), num_vertices)
-        cache = (fv32, cidx, num_vertices)
-        fv._geobi_fv = cache
+        mark_face_table(fv, fv32, num_vertices)
+        cache = fv._geobi_fv
     return cache[0], cache[1]
 
 
@@ -103,7 +121,11 @@ class DualGNN(nn.Module):
             verts, normals = DualGNNFn.apply(self, data_v, data_f, *params)
         else:
             with torch.no_grad():
-                verts, normals, _ = self._forward_impl(data_v, data_f, ops.Tape(record=False))
+                fast = executor.forward(self, data_v, data_f)       # the whole pass as one library call
+                if fast is not None:
+                    verts, normals = fast
+                else:
+                    verts, normals, _ = self._forward_impl(data_v, data_f, ops.Tape(record=False))
         return verts, normals, None
 
     def _forward_impl(self, data_v, data_f, tape):

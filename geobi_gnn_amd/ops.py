@@ -251,6 +251,14 @@ class SegmentIndex(object):
                    L.ptr(self.members), L.ptr(ws), ws.numel(), L.stream())
 
     @staticmethod
+    def view(seg32, nseg, segptr, members):
+        """Lists that already exist (slices of arrays built with an upper bound on the sizes)."""
+        self = SegmentIndex.__new__(SegmentIndex)
+        self.seg, self.n, self.nseg = seg32, int(seg32.shape[0]), int(nseg)
+        self.segptr, self.members = segptr, members
+        return self
+
+    @staticmethod
     def from_matching(cnew32, raw32, nseg):
         """Sort-free lists for a matching (clusters of <= 2 nodes, raw id = smaller member)."""
         self = SegmentIndex(cnew32, nseg, build=False)
@@ -368,7 +376,7 @@ class FaceGeomFn(Function):
     @staticmethod
     def backward(ctx, gout):
         verts, fv32 = ctx.saved_tensors
-        cidx = ctx.corner_index
+        cidx = ctx.corner_index.get() if hasattr(ctx.corner_index, 'get') else ctx.corner_index
         gout = _f32c(gout)
         F = fv32.shape[0]
         cg = torch.empty((3 * F, 3), dtype=torch.float32, device=gout.device)

@@ -304,6 +304,52 @@ int geobi_gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, i
  * `numel() == 0` syncs, code/net_util.py:128,139).                                                  */
 int geobi_read_i32(const int32_t* dev, int n, int32_t* host, void* stream);
 
+/* ---------------------------------------------------------------- whole-network forward ----
+ * The complete inference pass of code/network.py:318-343 (DualGNN.forward: vertex branch -> vertex head ->
+ * geometry coupling -> facet branch -> normal head) as ONE call: the op sequence of GNNModule.forward
+ * (code/network.py:270-300) and PoolingLayer.forward (code/net_util.py:76-158, edge_weight_type 10, two matching
+ * steps, max or mean pooling) is driven by native host code instead of ~180 Python-level launches.  Same kernels,
+ * same order, bit-identical results to the module-by-module path.
+ *   arena : caller-provided device scratch; every intermediate (features, coarse graphs, cluster vectors) is
+ *           bump-allocated in it and stays valid until the caller releases it.  geobi_net_forward_arena_bytes is a
+ *           sufficient size for a mesh of the given level-0 sizes.
+ *   graphs: loop-free, (row, col)-sorted, SYMMETRIC CSR of level 0 with the static edge weights in CSR order.
+ *   out   : byte offsets into the arena of the results and of what the module surface exposes afterwards
+ *           (PoolingLayer.unpooling_indices, the raw cluster vector of every matching step).
+ * Host synchronisation: one read of the pooling sizes per pooling layer (4 per call).
+ * Returns 0, or GEOBI_NET_FALLBACK (2) when a case outside the fast path turned up (edge-free level, a matching
+ * that needs more rounds, a coarse row beyond the sort-free width) -- the caller then runs the module-by-module
+ * path --, or GEOBI_NET_ARENA (3) when the arena is too small (out->used_bytes = bytes needed so far).        */
+#define GEOBI_NET_FALLBACK 2
+#define GEOBI_NET_ARENA 3
+typedef struct { const float *lin_w, *u_w, *c, *bias; } geobi_conv_params_t;
+typedef struct { geobi_conv_params_t conv[8]; } geobi_gnn_params_t;        /* l_conv1..4, r_conv1..4 */
+typedef struct {
+  geobi_gnn_params_t gnn_v, gnn_f;
+  const float *fc_v1_w, *fc_v1_b, *fc_v2_w, *fc_v2_b, *fc_f1_w, *fc_f1_b, *fc_f2_w, *fc_f2_b;
+  int32_t force_depth, pool_mean;
+} geobi_net_params_t;
+typedef struct {
+  int64_t N, E;
+  const int32_t *rowptr, *col, *row;
+  const float* weight;
+} geobi_level0_t;
+typedef struct {
+  int64_t nodes[3];               /* node count of levels 0, 1, 2 */
+  int64_t unpool_off[2];          /* int32 [nodes[l]]: composed fine -> coarse index of pooling layer l + 1 */
+  int64_t cluster_off[2][2];      /* int32 raw (graclus-style) cluster vector of [layer][step] */
+  int64_t cluster_len[2][2];
+} geobi_branch_out_t;
+typedef struct {
+  int64_t verts_off, normals_off, xf_off;     /* float [V,3], [F,3], [F,12] */
+  int64_t used_bytes;
+  geobi_branch_out_t v, f;
+} geobi_net_out_t;
+size_t geobi_net_forward_arena_bytes(int64_t V, int64_t Ev, int64_t F, int64_t Ef);
+int geobi_net_forward(const geobi_net_params_t* prm, const geobi_level0_t* gv, const geobi_level0_t* gf,
+                      const float* x_v, const float* x_f, const int32_t* fv, const float* depth_direction,
+                      void* arena, size_t arena_bytes, geobi_net_out_t* out, void* stream);
+
 /* ---------------------------------------------------------------- concurrency --------------
  * Weight-gradient GEMMs are off the critical path of a backward call; by default they run on a
  * library-owned non-blocking HIP stream, forked from and joined back into `stream` INSIDE the call

@@ -872,3 +872,48 @@ def test_training_driver_two_epochs_writes_reference_loadable_checkpoint(dev, tm
             tot += network.error_n(nh, df.y.to(dev)).item() * df.y.shape[0]
             cnt += df.y.shape[0]
     assert abs(tot / cnt - best['eval_error_f_deg']) < 1e-3
+
+
+@pytest.mark.parametrize('n,pool_type,force_depth', [(6, 'max', False), (16, 'max', False), (11, 'mean', False),
+                                                     (8, 'max', True), (32, 'max', False)])
+def test_whole_network_executor_equals_module_path(dev, n, pool_type, force_depth):
+    """geobi_net_forward (the inference pass as ONE library call, native host code) against the module-by-module path:
+    same kernels in the same order, so outputs, cluster vectors and unpool indices are bit-identical."""
+    from geobi_gnn_amd import network, meshgen, executor
+    torch.manual_seed(n)
+    net = network.DualGNN(force_depth=force_depth, pool_type=pool_type).to(dev).eval()
+    dv, df = meshgen.synthetic_dual_data(n, 0.2, seed=n, data_type='Kinect_v1' if force_depth else 'Synthetic')
+    dv, df = dv.to(dev), df.to(dev)
+    mods = (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2)
+
+    def run(enabled):
+        was = executor.ENABLED
+        executor.ENABLED = enabled
+        try:
+            a, b = dv.shallow_copy(), df.shallow_copy()
+            with torch.no_grad():
+                vp, npred, _ = net((a, b))
+            state = [[c.clone() for c in m.last_clusters] for m in mods], [m.unpooling_indices.clone() for m in mods]
+            return vp.clone(), npred.clone(), state
+        finally:
+            executor.ENABLED = was
+
+    v0, n0, (cl0, un0) = run(False)
+    assert executor.supported(net)
+    v1, n1, (cl1, un1) = run(True)
+    assert torch.equal(v0, v1) and torch.equal(n0, n1)
+    for a, b in zip(un0, un1):
+        assert torch.equal(a, b)
+    for la, lb in zip(cl0, cl1):
+        assert len(la) == len(lb) == 2
+        for a, b in zip(la, lb):
+            assert torch.equal(a, b)
+    # the module surface keeps working after an executor pass
+    x = torch.randn(int(un1[0].max()) + 1, 5, device=dev)
+    assert torch.equal(net.gnn_v.pooling1.unpooling(x), x[un1[0]])
+    # a network outside the fast path (other edge-weight type) silently takes the module path
+    other = network.DualGNN(edge_weight_type=0).to(dev).eval()
+    assert not executor.supported(other)
+    with torch.no_grad():
+        vo, no, _ = other((dv.shallow_copy(), df.shallow_copy()))
+    assert bool(torch.isfinite(vo).all()) and bool(torch.isfinite(no).all())

@@ -223,3 +223,30 @@ def test_patch_scatter_two_ranks_on_one_device(dev, tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
+
+
+def test_executor_on_open_patches_equals_module_path(dev):
+    """Patches are open meshes (boundaries, irregular valences): the cases where a matching needs more than the default
+    rounds or a coarse row exceeds the sort-free width are repaired inside the whole-network executor; the merged result
+    is bit-identical to the module-by-module path and no call falls back."""
+    from geobi_gnn_amd import network, patches, executor
+    n, (noisy, clean, faces) = _c2_mesh(3)
+    pts = torch.from_numpy(noisy).to(dev)
+    fv = torch.from_numpy(faces).to(dev).int().contiguous()
+    torch.manual_seed(0)
+    net = network.DualGNN().to(dev).eval()
+    was = executor.ENABLED
+    try:
+        executor.ENABLED = False
+        ref = patches.predict_mesh(net, pts, fv, sub_size=6000, n_iter=5, patch_batch=3)
+        executor.ENABLED = True
+        before = dict(executor.STATS)
+        out = patches.predict_mesh(net, pts, fv, sub_size=6000, n_iter=5, patch_batch=3)
+        one = patches.predict_mesh(net, pts, fv, sub_size=6000, n_iter=5, patch_batch=1)
+    finally:
+        executor.ENABLED = was
+    assert out['n_patches'] == ref['n_patches'] >= 7
+    assert torch.equal(out['Np'], ref['Np']) and torch.equal(out['Vp'], ref['Vp'])
+    assert torch.equal(one['Np'], ref['Np']) and torch.equal(one['Vp'], ref['Vp'])
+    assert executor.STATS['calls'] - before['calls'] >= 3 + out['n_patches']
+    assert executor.STATS['fallback'] == before['fallback']

@@ -7,7 +7,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../geobi_gnn_amd/csrc" && pwd)"
 mkdir -p "$HERE/build/variants"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function "$@" -c "$HERE/$UNIT.hip" -o "$HERE/build/variants/${UNIT}_$NAME.o" 2>&1 | grep -E "error|Spill: [1-9]" || true
 OBJS=()
-for f in capi graph gemm feast feast_fused pool geom head_fused meshprep patch; do
+for f in capi executor graph gemm feast feast_fused pool geom head_fused meshprep patch; do
   if [ "$f" = "$UNIT" ]; then OBJS+=("$HERE/build/variants/${UNIT}_$NAME.o"); else OBJS+=("$HERE/build/$f.o"); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$HERE/build/variants/libgeobi_hip_$NAME.so" "${OBJS[@]}"
