@@ -18,7 +18,41 @@ constexpr int kFallback = GEOBI_NET_FALLBACK;
 struct Level {
   int64_t N = 0, E = 0;
   const int32_t *rowptr = nullptr, *col = nullptr, *row = nullptr;
+  const int32_t* pos_rev = nullptr;      // position of the reverse edge (training: the backward's transposition)
   const float* w = nullptr;
+};
+
+// What the backward of one op needs (host-side record of a training forward; device data lives in the arena)
+struct ConvSave {
+  const Level* g = nullptr;
+  const float *xa = nullptr, *xb = nullptr;
+  int Ca = 0, Cb = 0, Cout = 0;
+  float slope = 1.f;
+  const geobi_conv_params_t* p = nullptr;
+  float *out = nullptr, *logits = nullptr, *wf = nullptr;
+};
+struct PoolSave {
+  int C = 0, pool_mean = 0;
+  int64_t P = 0, R1 = 0, R2 = 0;
+  const int32_t *seg[2] = {nullptr, nullptr}, *segptr[2] = {nullptr, nullptr};
+  const int32_t* arg[2] = {nullptr, nullptr};
+  const int32_t *segptr12 = nullptr, *members12 = nullptr;     // fine -> coarse inverse lists (unpool backward)
+};
+struct BranchTape {
+  Level L[3];
+  ConvSave conv[8];
+  PoolSave pool[2];
+  int Cin = 0;
+};
+struct NetTape {
+  geobi_net_params_t prm;
+  BranchTape v, f;
+  int64_t V = 0, F = 0;
+  const float *x_v = nullptr, *dd = nullptr;
+  const int32_t* fv = nullptr;
+  float *feat_v = nullptr, *feat_f = nullptr, *raw_v = nullptr, *raw_f = nullptr, *verts = nullptr;
+  char* arena = nullptr;
+  size_t arena_bytes = 0, fwd_peak = 0;
 };
 
 // Bump allocator over the caller's arena.  Results are taken first, per-call scratch after a mark that is released
@@ -47,19 +81,29 @@ __global__ void compose_index_kernel(const int32_t* __restrict__ first, const in
   if (i < n) out[i] = second[first[i]];
 }
 
-// FeaStConv forward (no gradient): `out` is a result, logits and workspace are scratch
+// FeaStConv forward.  Inference: logits and workspace are scratch.  Training (`save`): logits and the packed weights
+// stay for the backward.
 int conv_fwd(Bump& b, const Level& g, const float* xa, const float* xb, int Ca, int Cb, const geobi_conv_params_t& p,
-             int Cout, float slope, float** out, hipStream_t s) {
+             int Cout, float slope, float** out, ConvSave* save, hipStream_t s) {
   const int64_t N = g.N;
   float* o = b.take<float>((size_t)N * Cout);
+  float *logits = nullptr, *wf = nullptr;
+  if (save) {
+    logits = b.take<float>((size_t)N * GEOBI_HP);
+    wf = b.take<float>(feast_wpack_floats(Ca + Cb, Cout));
+  }
   const size_t m = b.mark();
-  float* logits = b.take<float>((size_t)N * GEOBI_HP);
+  if (!save) logits = b.take<float>((size_t)N * GEOBI_HP);
   const size_t wsb = feast_fwd_ws_bytes(N, Ca + Cb, Cout);
   void* ws = b.take<char>(wsb);
   if (!b.ok) return kArenaFull;
   GEOBI_TRY(feast_fwd(xa, Cb ? xb : nullptr, Ca, Cb, N, g.E, g.rowptr, g.col, p.lin_w, p.u_w, p.c, p.bias, Cout, slope, o,
-                      logits, nullptr, nullptr, ws, wsb, s));
+                      logits, nullptr, wf, ws, wsb, s));
   b.release(m);
+  if (save) {
+    save->g = &g; save->xa = xa; save->xb = Cb ? xb : nullptr; save->Ca = Ca; save->Cb = Cb; save->Cout = Cout;
+    save->slope = slope; save->p = &p; save->out = o; save->logits = logits; save->wf = wf;
+  }
   *out = o;
   return 0;
 }
@@ -75,7 +119,8 @@ struct PoolResult {
 // PoolingLayer.forward with edge_weight_type 10 and two matching steps: the integer pipeline of both steps is
 // enqueued back to back (the second on the first's coarse graph padded to the fine node count, see
 // net_util._coarsen_chain), ONE read-back returns the sizes, the features follow with exact sizes.
-int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, PoolResult& r, hipStream_t s) {
+int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, PoolResult& r, PoolSave* save,
+               hipStream_t s) {
   const int64_t P = g.N, E = g.E;
   if (E <= 0 || P <= 0) return kFallback;
   // ---- results of the integer pipeline (kept: graphs, lists, cluster vectors)
@@ -157,19 +202,35 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   float* x1 = b.take<float>((size_t)R1 * C);
   float* x2 = b.take<float>((size_t)R2 * C);
   int32_t* unpool = b.take<int32_t>(P);
+  int32_t *arg1 = nullptr, *arg2 = nullptr, *segptr12 = nullptr, *members12 = nullptr, *pos_rev = nullptr;
+  if (save) {       // training: arg-max rows, the composed inverse lists and the coarse level's reverse-edge index stay
+    arg1 = b.take<int32_t>((size_t)R1 * C); arg2 = b.take<int32_t>((size_t)R2 * C);
+    segptr12 = b.take<int32_t>(R2 + 1); members12 = b.take<int32_t>(P);
+    pos_rev = b.take<int32_t>(E2);
+  }
   const size_t m2 = b.mark();
-  int32_t* arg = b.take<int32_t>((size_t)R1 * C);
+  if (!save) { arg1 = b.take<int32_t>((size_t)R1 * C); arg2 = arg1; }
+  const size_t cws = segment_pairs_ws_bytes(R2);
+  void* ws_c = save ? b.take<char>(cws) : nullptr;
   if (!b.ok) return kArenaFull;
   if (pool_mean) {
     GEOBI_TRY(segment_sum(x, C, segptr[0], members[0], R1, 1, x1, s));
     GEOBI_TRY(segment_sum(x1, C, segptr[1], members[1], R2, 1, x2, s));
   } else {
-    GEOBI_TRY(segment_max_fwd(x, C, segptr[0], members[0], R1, x1, arg, s));
-    GEOBI_TRY(segment_max_fwd(x1, C, segptr[1], members[1], R2, x2, arg, s));
+    GEOBI_TRY(segment_max_fwd(x, C, segptr[0], members[0], R1, x1, arg1, s));
+    GEOBI_TRY(segment_max_fwd(x1, C, segptr[1], members[1], R2, x2, arg2, s));
   }
   compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
   GEOBI_LAUNCH_OK();
+  if (save) {
+    GEOBI_TRY(segment_csr_compose(segptr[0], members[0], segptr[1], members[1], R2, P, segptr12, members12, ws_c, cws, s));
+    GEOBI_TRY(csr_reverse_index(rowptr_c[1], row_c[1], col_c[1], E2, pos_rev, nullptr, s));
+    save->C = C; save->pool_mean = pool_mean; save->P = P; save->R1 = R1; save->R2 = R2;
+    save->seg[0] = cnew[0]; save->seg[1] = cnew[1]; save->segptr[0] = segptr[0]; save->segptr[1] = segptr[1];
+    save->arg[0] = arg1; save->arg[1] = arg2; save->segptr12 = segptr12; save->members12 = members12;
+  }
   b.release(m2);
+  r.coarse.pos_rev = pos_rev;
   r.coarse.N = R2; r.coarse.E = E2;
   r.coarse.rowptr = rowptr_c[1]; r.coarse.col = col_c[1]; r.coarse.row = row_c[1]; r.coarse.w = w_c[1];
   r.x = x2; r.unpool = unpool;
@@ -188,23 +249,30 @@ int unpool_rows(Bump& b, const float* x, const int32_t* idx, int C, int64_t n, f
 
 // GNNModule.forward (network.py:270-300): channel plan Cin -> 32 | 64 | 128, 128 | 64, 64 | 32, 32
 int gnn_forward(Bump& b, const Level& L0, const float* x_in, int Cin, const geobi_gnn_params_t& p, int pool_mean,
-                float** feat, geobi_branch_out_t& bo, hipStream_t s) {
+                float** feat, geobi_branch_out_t& bo, BranchTape* tape, hipStream_t s) {
   float *x0, *x1, *x2a, *x2, *up2, *r1, *x1b, *up1, *r3, *out;
-  GEOBI_TRY(conv_fwd(b, L0, x_in, nullptr, Cin, 0, p.conv[0], 32, kLeak, &x0, s));
   PoolResult p1, p2;
-  GEOBI_TRY(pool_layer(b, L0, x0, 32, pool_mean, p1, s));
-  const Level& L1 = p1.coarse;
-  GEOBI_TRY(conv_fwd(b, L1, p1.x, nullptr, 32, 0, p.conv[1], 64, kLeak, &x1, s));
-  GEOBI_TRY(pool_layer(b, L1, x1, 64, pool_mean, p2, s));
-  const Level& L2 = p2.coarse;
-  GEOBI_TRY(conv_fwd(b, L2, p2.x, nullptr, 64, 0, p.conv[2], 128, kLeak, &x2a, s));
-  GEOBI_TRY(conv_fwd(b, L2, x2a, nullptr, 128, 0, p.conv[3], 128, kLeak, &x2, s));
+  Level L1s, L2s;
+  // levels referenced by the saved records must outlive this call: they live in the tape when there is one
+  Level& L0r = tape ? tape->L[0] : const_cast<Level&>(L0);
+  if (tape) { tape->L[0] = L0; tape->Cin = Cin; }
+  auto cs = [&](int i) { return tape ? &tape->conv[i] : nullptr; };
+  GEOBI_TRY(conv_fwd(b, L0r, x_in, nullptr, Cin, 0, p.conv[0], 32, kLeak, &x0, cs(0), s));
+  GEOBI_TRY(pool_layer(b, L0r, x0, 32, pool_mean, p1, tape ? &tape->pool[0] : nullptr, s));
+  Level& L1 = tape ? tape->L[1] : L1s;
+  L1 = p1.coarse;
+  GEOBI_TRY(conv_fwd(b, L1, p1.x, nullptr, 32, 0, p.conv[1], 64, kLeak, &x1, cs(1), s));
+  GEOBI_TRY(pool_layer(b, L1, x1, 64, pool_mean, p2, tape ? &tape->pool[1] : nullptr, s));
+  Level& L2 = tape ? tape->L[2] : L2s;
+  L2 = p2.coarse;
+  GEOBI_TRY(conv_fwd(b, L2, p2.x, nullptr, 64, 0, p.conv[2], 128, kLeak, &x2a, cs(2), s));
+  GEOBI_TRY(conv_fwd(b, L2, x2a, nullptr, 128, 0, p.conv[3], 128, kLeak, &x2, cs(3), s));
   GEOBI_TRY(unpool_rows(b, x2, p2.unpool, 128, L1.N, &up2, s));
-  GEOBI_TRY(conv_fwd(b, L1, up2, nullptr, 128, 0, p.conv[4], 64, 1.0f, &r1, s));
-  GEOBI_TRY(conv_fwd(b, L1, x1, r1, 64, 64, p.conv[5], 64, kLeak, &x1b, s));
+  GEOBI_TRY(conv_fwd(b, L1, up2, nullptr, 128, 0, p.conv[4], 64, 1.0f, &r1, cs(4), s));
+  GEOBI_TRY(conv_fwd(b, L1, x1, r1, 64, 64, p.conv[5], 64, kLeak, &x1b, cs(5), s));
   GEOBI_TRY(unpool_rows(b, x1b, p1.unpool, 64, L0.N, &up1, s));
-  GEOBI_TRY(conv_fwd(b, L0, up1, nullptr, 64, 0, p.conv[6], 32, 1.0f, &r3, s));
-  GEOBI_TRY(conv_fwd(b, L0, x0, r3, 32, 32, p.conv[7], 32, kLeak, &out, s));
+  GEOBI_TRY(conv_fwd(b, L0r, up1, nullptr, 64, 0, p.conv[6], 32, 1.0f, &r3, cs(6), s));
+  GEOBI_TRY(conv_fwd(b, L0r, x0, r3, 32, 32, p.conv[7], 32, kLeak, &out, cs(7), s));
   *feat = out;
   bo.nodes[0] = L0.N; bo.nodes[1] = L1.N; bo.nodes[2] = L2.N;
   const PoolResult* pr[2] = {&p1, &p2};
@@ -214,6 +282,117 @@ int gnn_forward(Bump& b, const Level& L0, const float* x_in, int Cin, const geob
       bo.cluster_off[l][t] = b.offset_of(pr[l]->raw[t]);
       bo.cluster_len[l][t] = pr[l]->raw_len[t];
     }
+  }
+  return 0;
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ bsrc, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += bsrc[i];
+}
+
+// Backward of one FeaStConv from its saved record; gradients w.r.t. the input halves go to dxa / dxb (nullable)
+int conv_bwd(Bump& b, const ConvSave& c, const geobi_conv_params_t& grad, const float* gout, float* dxa, float* dxb,
+             int accumulate, hipStream_t s) {
+  const Level& g = *c.g;
+  const size_t m = b.mark();
+  const size_t wsb = feast_bwd_ws_bytes(g.N, g.E, c.Ca + c.Cb, c.Cout);
+  void* ws = b.take<char>(wsb);
+  if (!b.ok) return kArenaFull;
+  GEOBI_TRY(feast_bwd(c.xa, c.xb, c.Ca, c.Cb, g.N, g.E, g.rowptr, g.col, g.rowptr, g.col, g.pos_rev, c.p->lin_w, c.p->u_w,
+                      c.p->c, c.Cout, c.slope, c.out, gout, c.logits, nullptr, c.wf, dxa, dxb, (float*)grad.lin_w,
+                      (float*)grad.u_w, (float*)grad.c, (float*)grad.bias, accumulate, ws, wsb, s));
+  // the side stream may still read the workspace (weight-gradient GEMMs, joined once at the end of the backward):
+  // scratch of consecutive layers must not alias -> no release here; the backward region is bump-only
+  (void)m;
+  return 0;
+}
+
+// pooling backward: gradient of the pooled features [R2, C] -> gradient of the layer input [P, C]
+int pool_bwd(Bump& b, const PoolSave& p, const float* g2, float** gx, hipStream_t s) {
+  float* g1 = b.take<float>((size_t)p.R1 * p.C);
+  float* g0 = b.take<float>((size_t)p.P * p.C);
+  if (!b.ok) return kArenaFull;
+  if (p.pool_mean) {
+    GEOBI_TRY(segment_mean_bwd(g2, p.seg[1], p.segptr[1], p.C, p.R1, g1, s));
+    GEOBI_TRY(segment_mean_bwd(g1, p.seg[0], p.segptr[0], p.C, p.P, g0, s));
+  } else {
+    GEOBI_TRY(segment_max_bwd(g2, p.arg[1], p.seg[1], p.C, p.R2, p.R1, g1, s));
+    GEOBI_TRY(segment_max_bwd(g1, p.arg[0], p.seg[0], p.C, p.R1, p.P, g0, s));
+  }
+  *gx = g0;
+  return 0;
+}
+
+// GNNModule backward: g_out = gradient of the branch output [N0, 32]; dx_in (nullable) = gradient of its input
+int gnn_backward(Bump& b, const BranchTape& t, const geobi_gnn_params_t& grad, const float* g_out, float* dx_in,
+                 int accumulate, hipStream_t s) {
+  const int64_t N0 = t.L[0].N, N1 = t.L[1].N, N2 = t.L[2].N;
+  float* g_x0 = b.take<float>((size_t)N0 * 32);
+  float* g_r3 = b.take<float>((size_t)N0 * 32);
+  float* g_up1 = b.take<float>((size_t)N0 * 64);
+  float* g_x1b = b.take<float>((size_t)N1 * 64);
+  float* g_x1 = b.take<float>((size_t)N1 * 64);
+  float* g_r1 = b.take<float>((size_t)N1 * 64);
+  float* g_up2 = b.take<float>((size_t)N1 * 128);
+  float* g_x2 = b.take<float>((size_t)N2 * 128);
+  float* g_x2a = b.take<float>((size_t)N2 * 128);
+  float* g_x2p = b.take<float>((size_t)N2 * 64);
+  float* g_x1p = b.take<float>((size_t)N1 * 32);
+  if (!b.ok) return kArenaFull;
+  GEOBI_TRY(conv_bwd(b, t.conv[7], grad.conv[7], g_out, g_x0, g_r3, accumulate, s));
+  GEOBI_TRY(conv_bwd(b, t.conv[6], grad.conv[6], g_r3, g_up1, nullptr, accumulate, s));
+  GEOBI_TRY(segment_sum(g_up1, 64, t.pool[0].segptr12, t.pool[0].members12, N1, 0, g_x1b, s));
+  GEOBI_TRY(conv_bwd(b, t.conv[5], grad.conv[5], g_x1b, g_x1, g_r1, accumulate, s));
+  GEOBI_TRY(conv_bwd(b, t.conv[4], grad.conv[4], g_r1, g_up2, nullptr, accumulate, s));
+  GEOBI_TRY(segment_sum(g_up2, 128, t.pool[1].segptr12, t.pool[1].members12, N2, 0, g_x2, s));
+  GEOBI_TRY(conv_bwd(b, t.conv[3], grad.conv[3], g_x2, g_x2a, nullptr, accumulate, s));
+  GEOBI_TRY(conv_bwd(b, t.conv[2], grad.conv[2], g_x2a, g_x2p, nullptr, accumulate, s));
+  float* g_pool = nullptr;
+  GEOBI_TRY(pool_bwd(b, t.pool[1], g_x2p, &g_pool, s));
+  add_inplace_kernel<<<cdiv(N1 * 64, 256), 256, 0, s>>>(g_x1, g_pool, N1 * 64);      // skip (r_conv2) + pooling2 paths
+  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(conv_bwd(b, t.conv[1], grad.conv[1], g_x1, g_x1p, nullptr, accumulate, s));
+  GEOBI_TRY(pool_bwd(b, t.pool[0], g_x1p, &g_pool, s));
+  add_inplace_kernel<<<cdiv(N0 * 32, 256), 256, 0, s>>>(g_x0, g_pool, N0 * 32);      // skip (r_conv4) + pooling1 paths
+  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(conv_bwd(b, t.conv[0], grad.conv[0], g_x0, dx_in, nullptr, accumulate, s));
+  return 0;
+}
+
+int net_forward_impl(const geobi_net_params_t* prm, const geobi_level0_t* gv, const geobi_level0_t* gf, const float* x_v,
+                     const float* x_f, const int32_t* fv, const float* depth_direction, const int32_t* pos_rev_v,
+                     const int32_t* pos_rev_f, Bump& b, geobi_net_out_t* out, NetTape* tape, hipStream_t s) {
+  Level Lv, Lf;
+  Lv.N = gv->N; Lv.E = gv->E; Lv.rowptr = gv->rowptr; Lv.col = gv->col; Lv.row = gv->row; Lv.w = gv->weight;
+  Lf.N = gf->N; Lf.E = gf->E; Lf.rowptr = gf->rowptr; Lf.col = gf->col; Lf.row = gf->row; Lf.w = gf->weight;
+  Lv.pos_rev = pos_rev_v; Lf.pos_rev = pos_rev_f;
+  const int64_t V = Lv.N, F = Lf.N;
+  const geobi_net_params_t& P = tape ? tape->prm : *prm;       // saved records point into the tape's copy
+  float *feat_v = nullptr, *feat_f = nullptr;
+  GEOBI_TRY(gnn_forward(b, Lv, x_v, 6, P.gnn_v, P.pool_mean, &feat_v, out->v, tape ? &tape->v : nullptr, s));
+  // vertex head: fc_v2(leaky(fc_v1 .)) -> displacement (or depth along depth_direction) + xyz   (network.py:324-332)
+  const int nout_v = P.force_depth ? 1 : 3;
+  float* verts = b.take<float>((size_t)V * 3);
+  float* raw_v = b.take<float>((size_t)V * nout_v);
+  float* xf12 = b.take<float>((size_t)F * 12);
+  if (!b.ok) return kArenaFull;
+  GEOBI_TRY(head_fwd(feat_v, 32, V, P.fc_v1_w, P.fc_v1_b, 1024, P.fc_v2_w, P.fc_v2_b, nout_v, kLeak, 0,
+                     P.force_depth ? depth_direction : nullptr, x_v, 6, nullptr, raw_v, verts, s));
+  // geometry coupling: x_f = [x_f | centroid | unit normal] of the predicted geometry   (network.py:335-337)
+  GEOBI_TRY(face_geom_fwd(verts, fv, x_f, 6, F, xf12, s));
+  GEOBI_TRY(gnn_forward(b, Lf, xf12, 12, P.gnn_f, P.pool_mean, &feat_f, out->f, tape ? &tape->f : nullptr, s));
+  float* normals = b.take<float>((size_t)F * 3);
+  float* raw_f = b.take<float>((size_t)F * 3);
+  if (!b.ok) return kArenaFull;
+  GEOBI_TRY(head_fwd(feat_f, 32, F, P.fc_f1_w, P.fc_f1_b, 1024, P.fc_f2_w, P.fc_f2_b, 3, kLeak, 1, nullptr, nullptr, 0,
+                     nullptr, raw_f, normals, s));
+  out->verts_off = b.offset_of(verts);
+  out->normals_off = b.offset_of(normals);
+  out->xf_off = b.offset_of(xf12);
+  if (tape) {
+    tape->V = V; tape->F = F; tape->x_v = x_v; tape->dd = P.force_depth ? depth_direction : nullptr; tape->fv = fv;
+    tape->feat_v = feat_v; tape->feat_f = feat_f; tape->raw_v = raw_v; tape->raw_f = raw_f; tape->verts = verts;
   }
   return 0;
 }
@@ -239,43 +418,119 @@ extern "C" int geobi_net_forward(const geobi_net_params_t* prm, const geobi_leve
                                  void* arena, size_t arena_bytes, geobi_net_out_t* out, void* stream) {
   if (!prm || !gv || !gf || !x_v || !x_f || !fv || !arena || !out) return set_error("geobi_net_forward: null argument");
   if (prm->force_depth && !depth_direction) return set_error("geobi_net_forward: force_depth needs depth_direction");
-  hipStream_t s = (hipStream_t)stream;
   Bump b(arena, arena_bytes);
-  Level Lv, Lf;
-  Lv.N = gv->N; Lv.E = gv->E; Lv.rowptr = gv->rowptr; Lv.col = gv->col; Lv.row = gv->row; Lv.w = gv->weight;
-  Lf.N = gf->N; Lf.E = gf->E; Lf.rowptr = gf->rowptr; Lf.col = gf->col; Lf.row = gf->row; Lf.w = gf->weight;
-  const int64_t V = Lv.N, F = Lf.N;
+  int rc = net_forward_impl(prm, gv, gf, x_v, x_f, fv, depth_direction, nullptr, nullptr, b, out, nullptr, (hipStream_t)stream);
+  out->used_bytes = (int64_t)b.peak;
+  if (rc == kArenaFull) set_error("geobi_net_forward: arena too small (%zu bytes needed so far, %zu given)", b.peak, arena_bytes);
+  return rc;
+}
+
+extern "C" size_t geobi_net_train_arena_bytes(int64_t V, int64_t Ev, int64_t F, int64_t Ef) {
+  // forward records + the backward's scratch (one FeaSt backward workspace per layer: bump-only while the side stream
+  // may still read it), bounded by the level-0 sizes
+  auto branch = [](int64_t N, int64_t E) {
+    size_t w = 0;
+    const int cin[8] = {12, 32, 64, 128, 128, 128, 64, 64}, cout[8] = {32, 64, 128, 128, 64, 64, 32, 32};
+    const int lvl[8] = {0, 1, 2, 2, 1, 1, 0, 0};
+    for (int i = 0; i < 8; ++i) {
+      const int64_t n = lvl[i] == 0 ? N : (lvl[i] == 1 ? (N * 2) / 5 : N / 8);          // typical level sizes + margin
+      const int64_t e = lvl[i] == 0 ? E : (lvl[i] == 1 ? (E * 2) / 5 : E / 8);
+      w += feast_bwd_ws_bytes(n, e, cin[i], cout[i]);
+    }
+    return w + (size_t)N * 4 * 1024;
+  };
+  return geobi_net_forward_arena_bytes(V, Ev, F, Ef) + branch(V, Ev) + branch(F, Ef) + head_bwd_ws_bytes(V, 32, 1024) +
+         head_bwd_ws_bytes(F, 32, 1024) + ((size_t)64 << 20);
+}
+
+// Training forward: as geobi_net_forward, but everything the backward needs stays in the arena and a host-side
+// record of it is returned as `*handle` (release with geobi_net_release; the arena must outlive the backward).
+extern "C" int geobi_net_forward_train(const geobi_net_params_t* prm, const geobi_level0_t* gv, const geobi_level0_t* gf,
+                                       const int32_t* pos_rev_v, const int32_t* pos_rev_f, const float* x_v,
+                                       const float* x_f, const int32_t* fv, const float* depth_direction, void* arena,
+                                       size_t arena_bytes, geobi_net_out_t* out, int64_t* handle, void* stream) {
+  if (!prm || !gv || !gf || !pos_rev_v || !pos_rev_f || !x_v || !x_f || !fv || !arena || !out || !handle)
+    return set_error("geobi_net_forward_train: null argument");
+  if (prm->force_depth && !depth_direction) return set_error("geobi_net_forward_train: force_depth needs depth_direction");
+  NetTape* tape = new NetTape();
+  tape->prm = *prm;
+  tape->arena = (char*)arena; tape->arena_bytes = arena_bytes;
+  Bump b(arena, arena_bytes);
+  int rc = net_forward_impl(prm, gv, gf, x_v, x_f, fv, depth_direction, pos_rev_v, pos_rev_f, b, out, tape, (hipStream_t)stream);
+  out->used_bytes = (int64_t)b.peak;
+  if (rc != 0) {
+    if (rc == kArenaFull) set_error("geobi_net_forward_train: arena too small (%zu bytes needed so far, %zu given)", b.peak, arena_bytes);
+    delete tape;
+    *handle = 0;
+    return rc;
+  }
+  tape->fwd_peak = b.off;
+  *handle = (int64_t)(intptr_t)tape;
+  return 0;
+}
+
+extern "C" int geobi_net_release(int64_t handle) {
+  delete (NetTape*)(intptr_t)handle;
+  return 0;
+}
+
+// Backward of a recorded forward.  g_verts [V,3] / g_normals [F,3] (either may be NULL = zero); `grads` mirrors the
+// parameter struct (same order) and receives (accumulate != 0: is added) the parameter gradients.  corner_segptr /
+// corner_members: vertex -> corner inverse lists of the face table (the geometry coupling's gradient is summed through
+// them in a fixed order).  Scratch is taken from the rest of the forward's arena.
+extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals,
+                                  const geobi_net_params_t* grads, int accumulate, const int32_t* corner_segptr,
+                                  const int32_t* corner_members, void* stream) {
+  NetTape* t = (NetTape*)(intptr_t)handle;
+  if (!t || !grads || !corner_segptr || !corner_members) return set_error("geobi_net_backward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  Bump b(t->arena, t->arena_bytes);
+  b.off = b.peak = t->fwd_peak;
+  const geobi_net_params_t& P = t->prm;
+  const geobi_net_params_t& G = *grads;
+  const int64_t V = t->V, F = t->F;
+  const int nout_v = P.force_depth ? 1 : 3;
+  float* g_feat_f = b.take<float>((size_t)F * 32);
+  float* g_xf12 = b.take<float>((size_t)F * 12);
+  float* corner = b.take<float>((size_t)F * 9);
+  float* g_vsum = b.take<float>((size_t)V * 3);
+  float* g_feat_v = b.take<float>((size_t)V * 32);
+  float* zeros = nullptr;
+  if (!g_normals || !g_verts) zeros = b.take<float>((size_t)(F > V ? F : V) * 3);
+  const size_t hws_f = head_bwd_ws_bytes(F, 32, 1024), hws_v = head_bwd_ws_bytes(V, 32, 1024);
+  void* ws_hf = b.take<char>(hws_f);
+  void* ws_hv = b.take<char>(hws_v);
   auto fail = [&](int rc) {
-    out->used_bytes = (int64_t)b.peak;
-    if (rc == kArenaFull) set_error("geobi_net_forward: arena too small (%zu bytes needed so far, %zu given)", b.peak, arena_bytes);
+    (void)geobi_side_defer(0);
+    (void)geobi_side_join(stream);
+    if (rc == kArenaFull) set_error("geobi_net_backward: arena too small (%zu bytes needed so far, %zu given)", b.peak, t->arena_bytes);
     return rc;
   };
-  float *feat_v = nullptr, *feat_f = nullptr;
-  int rc = gnn_forward(b, Lv, x_v, 6, prm->gnn_v, prm->pool_mean, &feat_v, out->v, s);
-  if (rc) return fail(rc);
-  // vertex head: fc_v2(leaky(fc_v1 .)) -> displacement (or depth along depth_direction) + xyz   (network.py:324-332)
-  const int nout_v = prm->force_depth ? 1 : 3;
-  float* verts = b.take<float>((size_t)V * 3);
-  float* raw_v = b.take<float>((size_t)V * nout_v);
-  float* xf12 = b.take<float>((size_t)F * 12);
   if (!b.ok) return fail(kArenaFull);
-  rc = head_fwd(feat_v, 32, V, prm->fc_v1_w, prm->fc_v1_b, 1024, prm->fc_v2_w, prm->fc_v2_b, nout_v, kLeak, 0,
-                prm->force_depth ? depth_direction : nullptr, x_v, 6, nullptr, raw_v, verts, s);
+  if (zeros) GEOBI_HIP(hipMemsetAsync(zeros, 0, (size_t)(F > V ? F : V) * 3 * sizeof(float), s));
+  // weight-gradient GEMMs of every layer run on the side stream and are joined once, at the end
+  (void)geobi_side_defer(1);
+  int rc = head_bwd(t->feat_f, 32, F, P.fc_f1_w, P.fc_f1_b, 1024, P.fc_f2_w, 3, kLeak, 1, nullptr, nullptr, t->raw_f,
+                    g_normals ? g_normals : zeros, g_feat_f, (float*)G.fc_f1_w, (float*)G.fc_f1_b, (float*)G.fc_f2_w,
+                    (float*)G.fc_f2_b, accumulate, ws_hf, hws_f, s);
   if (rc) return fail(rc);
-  // geometry coupling: x_f = [x_f | centroid | unit normal] of the predicted geometry   (network.py:335-337)
-  rc = face_geom_fwd(verts, fv, x_f, 6, F, xf12, s);
+  rc = gnn_backward(b, t->f, G.gnn_f, g_feat_f, g_xf12, accumulate, s);
   if (rc) return fail(rc);
-  rc = gnn_forward(b, Lf, xf12, 12, prm->gnn_f, prm->pool_mean, &feat_f, out->f, s);
+  // geometry coupling: d[x_f | centroid | normal] -> per-corner gradients -> vertices (fixed-order segment sum)
+  rc = face_geom_bwd(t->verts, t->fv, g_xf12, F, corner, s);
   if (rc) return fail(rc);
-  float* normals = b.take<float>((size_t)F * 3);
-  float* raw_f = b.take<float>((size_t)F * 3);
-  if (!b.ok) return fail(kArenaFull);
-  rc = head_fwd(feat_f, 32, F, prm->fc_f1_w, prm->fc_f1_b, 1024, prm->fc_f2_w, prm->fc_f2_b, 3, kLeak, 1, nullptr, nullptr,
-                0, nullptr, raw_f, normals, s);
+  rc = segment_sum(corner, 3, corner_segptr, corner_members, V, 0, g_vsum, s);
   if (rc) return fail(rc);
-  out->verts_off = b.offset_of(verts);
-  out->normals_off = b.offset_of(normals);
-  out->xf_off = b.offset_of(xf12);
-  out->used_bytes = (int64_t)b.peak;
-  return 0;
+  if (g_verts) {
+    add_inplace_kernel<<<cdiv(V * 3, 256), 256, 0, s>>>(g_vsum, g_verts, V * 3);
+    if (hipGetLastError() != hipSuccess) return fail(set_error("geobi_net_backward: launch failed"));
+  }
+  rc = head_bwd(t->feat_v, 32, V, P.fc_v1_w, P.fc_v1_b, 1024, P.fc_v2_w, nout_v, kLeak, 0, t->dd, nullptr, t->raw_v, g_vsum,
+                g_feat_v, (float*)G.fc_v1_w, (float*)G.fc_v1_b, (float*)G.fc_v2_w, (float*)G.fc_v2_b, accumulate, ws_hv,
+                hws_v, s);
+  if (rc) return fail(rc);
+  rc = gnn_backward(b, t->v, G.gnn_v, g_feat_v, nullptr, accumulate, s);
+  if (rc) return fail(rc);
+  (void)geobi_side_defer(0);
+  return geobi_side_join(stream);
 }

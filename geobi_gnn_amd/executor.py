@@ -77,6 +77,37 @@ def _pack_params(net):
     return p, keep
 
 
+def _param_order(net):
+    """The parameters in the field order of geobi_net_params_t."""
+    out = []
+    for gname in ('gnn_v', 'gnn_f'):
+        mod = getattr(net, gname)
+        for cname in _CONVS:
+            c = getattr(mod, cname)
+            out += [c.lin.weight, c.u.weight, c.c, c.bias]
+    for fc in ('fc_v1', 'fc_v2', 'fc_f1', 'fc_f2'):
+        m = getattr(net, fc)
+        out += [m.weight, m.bias]
+    return out
+
+
+def _pack_pointers(tensors, net):
+    """A geobi_net_params_t over `tensors` (in _param_order)."""
+    p = _Params()
+    it = iter(tensors)
+    for gname in ('gnn_v', 'gnn_f'):
+        g = getattr(p, gname)
+        for i in range(8):
+            g.conv[i].lin_w, g.conv[i].u_w = next(it).data_ptr(), next(it).data_ptr()
+            g.conv[i].c, g.conv[i].bias = next(it).data_ptr(), next(it).data_ptr()
+    for fc in ('fc_v1', 'fc_v2', 'fc_f1', 'fc_f2'):
+        setattr(p, fc + '_w', next(it).data_ptr())
+        setattr(p, fc + '_b', next(it).data_ptr())
+    p.force_depth = 1 if net.force_depth else 0
+    p.pool_mean = 1 if net.gnn_v.pooling1.pool_type == 'mean' else 0
+    return p
+
+
 def supported(net):
     """The fast path covers the network as the reference builds it (edge_weight_type 10, two matching steps, no
     injected cluster vectors); everything else runs module by module."""
@@ -162,11 +193,107 @@ def forward(net, data_v, data_f):
     V, F = lv_v.N, lv_f.N
     verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
     normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
+    _set_module_state(net, arena, out)
+    return verts, normals
+
+
+def _set_module_state(net, arena, out):
+    """What the pooling modules expose after a forward (net_util.py:156): composed unpool index, raw cluster vectors."""
     for gname, bo in (('gnn_v', out.v), ('gnn_f', out.f)):
         mod = getattr(net, gname)
         for l, pl in enumerate((mod.pooling1, mod.pooling2)):
             pl._unpool32 = _views(arena, bo.unpool_off[l], bo.nodes[l], torch.int32)
             pl._unpool64 = None
-            pl._unpool_index = None                  # inverse lists are a training-time structure
+            pl._unpool_index = None                  # the executor keeps its own inverse lists
             pl._last_clusters32 = [_views(arena, bo.cluster_off[l][t], bo.cluster_len[l][t], torch.int32) for t in range(2)]
-    return verts, normals
+
+
+# ----------------------------------------------------------------------------------- training
+class Recorded(object):
+    """A training forward recorded by the library: the arena with every saved buffer, the host-side record (handle)
+    and what the backward needs from the Python side.  The record is released with the object."""
+
+    def __init__(self, handle, arena, keep, net, corner):
+        self.handle, self.arena, self.keep, self.net, self.corner = handle, arena, keep, net, corner
+
+    def release(self):
+        if self.handle:
+            L.lib().geobi_net_release(ctypes.c_int64(self.handle))
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def forward_train(net, data_v, data_f):
+    """-> (verts, normals, Recorded) or None (outside the fast path: the caller records the op tape instead)."""
+    from .network import _fv_index
+    if not (ENABLED and supported(net)):
+        return None
+    params = _param_order(net)
+    if not all(p.requires_grad for p in params) or data_v.x.requires_grad or data_f.x.requires_grad:
+        return None
+    keep = []
+    lv_v, lv_f = _level0(data_v, keep), _level0(data_f, keep)
+    if lv_v is None or lv_f is None or data_v.x.shape[1] != 6 or data_f.x.shape[1] != 6:
+        return None
+    gv, gf = data_v.graph().ensure_in(), data_f.graph().ensure_in()
+    dev = data_v.x.device
+    x_v, x_f = _f32(data_v.x, 'data_v.x'), _f32(data_f.x, 'data_f.x')
+    fv32, corner = _fv_index(data_f, x_v.shape[0])
+    dd = _f32(data_v.depth_direction, 'depth_direction') if net.force_depth else None
+    tensors = [_f32(p.detach(), 'parameter') for p in params]
+    prm = _pack_pointers(tensors, net)
+    keep += [tensors, x_v, x_f, fv32, dd, gv, gf]
+    lib = L.lib()
+    nbytes = L.size_query('geobi_net_train_arena_bytes', lv_v.N, lv_v.E, lv_f.N, lv_f.E)
+    out, handle = _Out(), ctypes.c_int64(0)
+    for _ in range(2):
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.geobi_net_forward_train(ctypes.byref(prm), ctypes.byref(lv_v), ctypes.byref(lv_f), gv.pos_in.data_ptr(),
+                                         gf.pos_in.data_ptr(), x_v.data_ptr(), x_f.data_ptr(), fv32.data_ptr(),
+                                         None if dd is None else dd.data_ptr(), arena.data_ptr(), nbytes,
+                                         ctypes.byref(out), ctypes.byref(handle), L.stream())
+        if rc != 3:
+            break
+        nbytes = max(2 * int(out.used_bytes), 2 * nbytes)
+        STATS['arena_retry'] += 1
+    STATS['calls'] += 1
+    if rc == 2:
+        STATS['fallback'] += 1
+        return None
+    if rc != 0:
+        L.check(rc, 'geobi_net_forward_train')
+    V, F = lv_v.N, lv_f.N
+    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3)
+    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3)
+    _set_module_state(net, arena, out)
+    return verts, normals, Recorded(handle.value, arena, keep, net, corner)
+
+
+def backward(rec, g_verts, g_normals, params):
+    """Parameter gradients of a recorded forward, aligned with `params` (None where the kernels added straight into a
+    direct-gradient bucket view, see ops._direct_grad)."""
+    from .ops import _direct_grad
+    net = rec.net
+    ordered = _param_order(net)
+    direct = [_direct_grad(p) for p in ordered]
+    use_direct = all(d is not None for d in direct)
+    grads = direct if use_direct else [torch.empty_like(p, memory_format=torch.contiguous_format) for p in ordered]
+    gp = _pack_pointers(grads, net)
+    cidx = rec.corner.get()
+    gv = None if g_verts is None else _f32(g_verts, 'grad of verts')
+    gn = None if g_normals is None else _f32(g_normals, 'grad of normals')
+    rc = L.lib().geobi_net_backward(ctypes.c_int64(rec.handle), None if gv is None else gv.data_ptr(),
+                                    None if gn is None else gn.data_ptr(), ctypes.byref(gp), 1 if use_direct else 0,
+                                    cidx.segptr.data_ptr(), cidx.members.data_ptr(), L.stream())
+    if rc != 0:
+        L.check(rc, 'geobi_net_backward')
+    rec.keep.append((gv, gn, grads))        # alive until the record goes (stream-ordered reuse is safe after that)
+    if use_direct:
+        return [None] * len(params)
+    by_id = {id(p): g for p, g in zip(ordered, grads)}
+    return [by_id.get(id(p)) for p in params]

@@ -156,6 +156,12 @@ class DualGNNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, data_v, data_f, *params):
+        ctx.recorded = None
+        fast = executor.forward_train(net, data_v, data_f)        # forward + record in one library call
+        if fast is not None:
+            verts, normals, ctx.recorded = fast
+            ctx.params = params
+            return verts, normals
         tape = ops.Tape(record=True)
         verts, normals, _ = net._forward_impl(data_v, data_f, tape)
         ctx.tape, ctx.verts, ctx.normals = tape, verts, normals
@@ -164,6 +170,13 @@ class DualGNNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_verts, g_normals):
+        if ctx.recorded is not None:
+            rec, ctx.recorded = ctx.recorded, None
+            grads = executor.backward(rec, g_verts, g_normals, ctx.params)
+            ctx.params = None
+            # the record (arena, host-side tape) goes when `rec` does; the backward's kernels are already enqueued and
+            # the caching allocator reuses the block in stream order
+            return (None, None, None) + tuple(grads)
         seeds = {}
         if g_verts is not None:
             seeds[id(ctx.verts)] = g_verts.contiguous()

@@ -350,6 +350,23 @@ int geobi_net_forward(const geobi_net_params_t* prm, const geobi_level0_t* gv, c
                       const float* x_v, const float* x_f, const int32_t* fv, const float* depth_direction,
                       void* arena, size_t arena_bytes, geobi_net_out_t* out, void* stream);
 
+/* Training through the same executor: geobi_net_forward_train additionally keeps what the backward needs in the arena
+ * (size: geobi_net_train_arena_bytes) and returns a host-side record of it as *handle; geobi_net_backward replays it
+ * in reverse -- the per-op backward passes of the module-by-module path, same kernels, same order -- and writes the
+ * 72 parameter gradients through `grads` (same layout as the parameter struct; accumulate != 0 adds, the semantics of
+ * autograd's accumulation into .grad, code/train_dual.py:211-218).  pos_rev_*: position of each level-0 edge's reverse
+ * edge (geobi_csr_reverse_index).  corner_segptr / corner_members: vertex -> corner inverse lists of the face table
+ * (geobi_segment_csr over fv viewed as [3F]).  The arena must stay untouched from the forward to the end of the
+ * backward; geobi_net_release frees the host-side record (after the backward, or instead of it).                  */
+size_t geobi_net_train_arena_bytes(int64_t V, int64_t Ev, int64_t F, int64_t Ef);
+int geobi_net_forward_train(const geobi_net_params_t* prm, const geobi_level0_t* gv, const geobi_level0_t* gf,
+                            const int32_t* pos_rev_v, const int32_t* pos_rev_f, const float* x_v, const float* x_f,
+                            const int32_t* fv, const float* depth_direction, void* arena, size_t arena_bytes,
+                            geobi_net_out_t* out, int64_t* handle, void* stream);
+int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals, const geobi_net_params_t* grads,
+                       int accumulate, const int32_t* corner_segptr, const int32_t* corner_members, void* stream);
+int geobi_net_release(int64_t handle);
+
 /* ---------------------------------------------------------------- concurrency --------------
  * Weight-gradient GEMMs are off the critical path of a backward call; by default they run on a
  * library-owned non-blocking HIP stream, forked from and joined back into `stream` INSIDE the call
