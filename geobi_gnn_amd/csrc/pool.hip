@@ -16,6 +16,7 @@
 // sequential statement of the same rule.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -173,6 +174,100 @@ __global__ void match_lists_kernel(const int* __restrict__ state, const int* __r
   }
   if (u == N - 1) {
     const int nc = rank[N];                            // exclusive scan over N + 1 entries: total at [N]
+    *count = nc;
+    segptr[nc] = N;
+  }
+}
+
+// Scan-free variant of (match_commit, exclusive scans, match_lists) for up to 256 * kMaxScanBlocks nodes: the commit
+// kernel scans its own 256 (flag, size) pairs in LDS and writes block-local prefixes plus one total per block; the
+// list kernel turns the <= kMaxScanBlocks totals into global prefixes in LDS at its start.  Two launches instead of
+// three, and no single-workgroup walk over the whole array.
+constexpr int kMaxScanBlocks = 4096;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* s_wave, int& total) {
+  // 256 threads = 4 waves; returns the exclusive prefix of v inside the block and the block total
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { const int t = s_wave[w]; off += w < wave ? t : 0; tot += t; }
+  __syncthreads();
+  total = tot;
+  return off + inc - v;
+}
+
+__global__ __launch_bounds__(256) void match_commit_scan_kernel(const int* __restrict__ prop, int N,
+                                                                int* __restrict__ cluster, int* __restrict__ remaining,
+                                                                int* __restrict__ final, int* __restrict__ lrank,
+                                                                int* __restrict__ loffs, int* __restrict__ bt_rank,
+                                                                int* __restrict__ bt_offs) {
+  __shared__ int s_wave[4];
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  int rep = 0, size = 0;
+  if (u < N) {
+    int st = cluster[u];
+    if (st < 0) {
+      int v = prop[u];
+      if (v == -1) st = u;
+      else if (v >= 0 && prop[v] == u) st = v;
+      else atomicAdd(remaining, 1);
+      if (st >= 0) cluster[u] = st;
+    }
+    const int fin = st < 0 ? u : (u < st ? u : st);
+    final[u] = fin;
+    rep = fin == u ? 1 : 0;
+    size = rep ? ((st >= 0 && st != u) ? 2 : 1) : 0;
+  }
+  int tr, to;
+  const int pr = block_exclusive_scan_256(rep, s_wave, tr);
+  const int po = block_exclusive_scan_256(size, s_wave, to);
+  if (u < N) { lrank[u] = pr; loffs[u] = po; }
+  if (threadIdx.x == 0) { bt_rank[blockIdx.x] = tr; bt_offs[blockIdx.x] = to; }
+}
+
+__global__ __launch_bounds__(256) void match_lists_scan_kernel(const int* __restrict__ state, const int* __restrict__ final,
+                                                               const int* __restrict__ lrank, const int* __restrict__ loffs,
+                                                               const int* __restrict__ bt_rank, const int* __restrict__ bt_offs,
+                                                               int nblocks, int N, int* __restrict__ cnew,
+                                                               int* __restrict__ count, int* __restrict__ segptr,
+                                                               int* __restrict__ members) {
+  // exclusive prefixes of the block totals (every block recomputes them: <= 4096 ints, L2-resident)
+  __shared__ int s_rank[kMaxScanBlocks], s_offs[kMaxScanBlocks];
+  __shared__ int s_wave[4];
+  __shared__ int s_total[2];
+  int carry_r = 0, carry_o = 0;
+  for (int base = 0; base < nblocks; base += 256) {
+    const int i = base + threadIdx.x;
+    const int vr = i < nblocks ? bt_rank[i] : 0, vo = i < nblocks ? bt_offs[i] : 0;
+    int tr, to;
+    const int pr = block_exclusive_scan_256(vr, s_wave, tr);
+    const int po = block_exclusive_scan_256(vo, s_wave, to);
+    if (i < nblocks) { s_rank[i] = carry_r + pr; s_offs[i] = carry_o + po; }
+    carry_r += tr; carry_o += to;
+  }
+  if (threadIdx.x == 0) { s_total[0] = carry_r; s_total[1] = carry_o; }
+  __syncthreads();
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= N) return;
+  const int rep = final[u];
+  cnew[u] = s_rank[rep >> 8] + lrank[rep];
+  if (rep == u) {
+    const int o = s_offs[u >> 8] + loffs[u];
+    segptr[s_rank[u >> 8] + lrank[u]] = o;
+    members[o] = u;
+    const int st = state[u];
+    if (st >= 0 && st != u) members[o + 1] = st;
+  }
+  if (u == N - 1) {
+    const int nc = s_total[0];
     *count = nc;
     segptr[nc] = N;
   }
@@ -764,6 +859,18 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
   int* pp = prop0;
   int* pn = prop1;
   launch_match_rounds(rowptr, col, w, (int)N, rounds, init, state, counters, pp, pn, s);
+  static const bool scan_free = [] { const char* f = getenv("GEOBI_MATCH_SCANFREE"); return !f || atoi(f) != 0; }();   // A/B knob
+  if (scan_free && blocks <= kMaxScanBlocks) {
+    // scan-free pair: block-local prefixes in the commit kernel, block totals folded by the list kernel
+    int* bt_rank = rank;                 // rank / offs are free in this variant: reuse them for the block totals
+    int* bt_offs = offs;
+    match_commit_scan_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz, bt_rank, bt_offs);
+    GEOBI_LAUNCH_OK();
+    match_lists_scan_kernel<<<blocks, 256, 0, s>>>(state, cluster_final, flag, sz, bt_rank, bt_offs, blocks, (int)N, cnew,
+                                                   counters + 1, segptr, members);
+    GEOBI_LAUNCH_OK();
+    return 0;
+  }
   match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
   GEOBI_LAUNCH_OK();
   if (N + 1 <= kSmallScan) {
