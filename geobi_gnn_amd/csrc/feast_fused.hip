@@ -147,10 +147,10 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
     const int re = valid ? rowptr[ns + 1] : rs;
     float(*slot)[HP] = S::SLOT_IN_ROW ? reinterpret_cast<float(*)[HP]>(zrow)
                                       : reinterpret_cast<float(*)[HP]>(s_slots + (wave * 64 + g * G) * HP);
-    float pc[H];
+    // the centre's logit row is re-read (L1) at the top of every chunk instead of living in 9 registers across the
+    // row-gather loop: that is what lets four neighbour rows be in flight at once within the 128-register budget
     float xc[LC > 0 ? LC : 1];
     if constexpr (LC > 0) load_row<LC>(xl + (size_t)ns * LC, xc);
-    else load_hp(p + (size_t)ns * HP, pc);
     {
       float xs[VEC];
 #pragma unroll
@@ -170,6 +170,12 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
         int j = ns;
         if (e < re) {
           j = col[e];
+          float pc[H];
+          if constexpr (LC == 0) {
+            const float* prow = p + (size_t)ns * HP;
+            asm volatile("" : "+v"(prow));            // keep the load inside the loop
+            load_hp(prow, pc);
+          }
           if constexpr (LC > 0) {
             float d[LC];
             load_row<LC>(xl + (size_t)j * LC, d);
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
 #ifdef GEOBI_FUSED_UNR
       constexpr int UNR = GEOBI_FUSED_UNR;          // tuning builds (tools/build_variant.sh)
 #else
-      constexpr int UNR = VEC < 4 ? 4 : 2;
+      constexpr int UNR = VEC <= 4 ? 4 : 2;
 #endif
       const int cnt = min(G, re - base);
       if (act) {
