@@ -360,6 +360,27 @@ int gnn_backward(Bump& b, const BranchTape& t, const geobi_gnn_params_t& grad, c
   return 0;
 }
 
+// Exact arena need of geobi_net_backward for a recorded forward (mirrors its allocations; the level sizes are known
+// once the forward has run, so the training forward can refuse an arena the backward would overflow)
+size_t branch_backward_bytes(const BranchTape& t) {
+  const int64_t N0 = t.L[0].N, N1 = t.L[1].N, N2 = t.L[2].N;
+  auto f = [](int64_t n) { return align_up((size_t)(n ? n : 1) * sizeof(float)); };
+  size_t b = f(N0 * 32) * 2 + f(N0 * 64) + f(N1 * 64) * 3 + f(N1 * 128) + f(N2 * 128) * 2 + f(N2 * 64) + f(N1 * 32);
+  for (int i = 0; i < 8; ++i) {
+    const ConvSave& c = t.conv[i];
+    b += align_up(feast_bwd_ws_bytes(c.g->N, c.g->E, c.Ca + c.Cb, c.Cout));
+  }
+  for (int l = 0; l < 2; ++l) b += f(t.pool[l].R1 * t.pool[l].C) + f(t.pool[l].P * t.pool[l].C);
+  return b;
+}
+size_t net_backward_bytes(const NetTape& t) {
+  auto f = [](int64_t n) { return align_up((size_t)(n ? n : 1) * sizeof(float)); };
+  const int64_t V = t.V, F = t.F;
+  return f(F * 32) + f(F * 12) + f(F * 9) + f(V * 3) + f(V * 32) + f((F > V ? F : V) * 3) +
+         align_up(head_bwd_ws_bytes(F, 32, 1024)) + align_up(head_bwd_ws_bytes(V, 32, 1024)) + branch_backward_bytes(t.v) +
+         branch_backward_bytes(t.f) + 4096;
+}
+
 int net_forward_impl(const geobi_net_params_t* prm, const geobi_level0_t* gv, const geobi_level0_t* gf, const float* x_v,
                      const float* x_f, const int32_t* fv, const float* depth_direction, const int32_t* pos_rev_v,
                      const int32_t* pos_rev_f, Bump& b, geobi_net_out_t* out, NetTape* tape, hipStream_t s) {
@@ -465,6 +486,14 @@ extern "C" int geobi_net_forward_train(const geobi_net_params_t* prm, const geob
     return rc;
   }
   tape->fwd_peak = b.off;
+  const size_t need = align_up(b.off) + net_backward_bytes(*tape);
+  out->used_bytes = (int64_t)need;              // forward + backward: what an arena for this mesh must hold
+  if (need > arena_bytes) {
+    set_error("geobi_net_forward_train: arena too small for the backward (%zu bytes needed, %zu given)", need, arena_bytes);
+    delete tape;
+    *handle = 0;
+    return kArenaFull;
+  }
   *handle = (int64_t)(intptr_t)tape;
   return 0;
 }

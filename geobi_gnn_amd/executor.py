@@ -209,6 +209,8 @@ def _set_module_state(net, arena, out):
 
 
 # ----------------------------------------------------------------------------------- training
+_LEARNED = {}       # (V, Ev, F, Ef) -> arena bytes that were enough for forward AND backward of that shape
+
 class Recorded(object):
     """A training forward recorded by the library: the arena with every saved buffer, the host-side record (handle)
     and what the backward needs from the Python side.  The record is released with the object."""
@@ -249,9 +251,11 @@ def forward_train(net, data_v, data_f):
     prm = _pack_pointers(tensors, net)
     keep += [tensors, x_v, x_f, fv32, dd, gv, gf]
     lib = L.lib()
-    nbytes = L.size_query('geobi_net_train_arena_bytes', lv_v.N, lv_v.E, lv_f.N, lv_f.E)
+    shape_key = (lv_v.N, lv_v.E, lv_f.N, lv_f.E)
+    nbytes = _LEARNED.get(shape_key) or L.size_query('geobi_net_train_arena_bytes', *shape_key)
     out, handle = _Out(), ctypes.c_int64(0)
-    for _ in range(2):
+    for _ in range(4):
+        arena = None                                   # release a too-small block before taking a larger one
         arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         rc = lib.geobi_net_forward_train(ctypes.byref(prm), ctypes.byref(lv_v), ctypes.byref(lv_f), gv.pos_in.data_ptr(),
                                          gf.pos_in.data_ptr(), x_v.data_ptr(), x_f.data_ptr(), fv32.data_ptr(),
@@ -259,7 +263,8 @@ def forward_train(net, data_v, data_f):
                                          ctypes.byref(out), ctypes.byref(handle), L.stream())
         if rc != 3:
             break
-        nbytes = max(2 * int(out.used_bytes), 2 * nbytes)
+        used = int(out.used_bytes)       # mid-forward overflow: bytes so far; end-of-forward check: the exact total
+        nbytes = int(1.25 * used) + (64 << 20) if used > nbytes else 2 * nbytes
         STATS['arena_retry'] += 1
     STATS['calls'] += 1
     if rc == 2:
@@ -267,6 +272,9 @@ def forward_train(net, data_v, data_f):
         return None
     if rc != 0:
         L.check(rc, 'geobi_net_forward_train')
+    # the library reports the exact need (forward + backward) of this mesh: later steps on the same shape take that
+    _LEARNED[shape_key] = int(1.05 * int(out.used_bytes)) + (16 << 20)
+    STATS['train_arena_bytes'], STATS['train_need_bytes'] = nbytes, int(out.used_bytes)
     V, F = lv_v.N, lv_f.N
     verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3)
     normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3)
