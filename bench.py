@@ -91,9 +91,13 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
     lib.geobi_prof_enable(0)
     ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
     lc = best['cin'] if best['cin'] in (6, 12) else 0
-    kname = 'feast_fused_kernel<%d,%d,0,%d,%d>' % (best['cin'], 3 if best['cin'] in (6, 12) else 4, lc, best['cout'] // 32)
+    kname = 'feast_fused_kernel<%d,0,%d,%d>' % (best['cin'], lc, best['cout'] // 32)     # <C, MODE, LC, NT>
     avg_us = best['ms'] * 1e3 / best['launches']
     traffic, traffic_src = pmc_traffic(kname)
+    # the same kernel against its other ceiling: the node transform on the fp32 matrix cores (2 N 9 Cin Cout flops per
+    # launch; the dominant layer runs on both level-0 graphs, N averaged over its launches)
+    n_avg = (dv.x.shape[0] + df.x.shape[0]) / 2.0
+    tflops = 2.0 * n_avg * 9 * best['cin'] * best['cout'] / (avg_us * 1e-6) / 1e12
     out = {
         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(ach / HBM_PEAK_GBS, 4),
@@ -102,6 +106,9 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
         'traffic': traffic, 'traffic_source': traffic_src,
         'frac_by_counters': None if traffic is None else round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
         'kernel': kname, 'layer': 'FeaStConv %d -> %d' % (best['cin'], best['cout']),
+        'mfma_side': {'achieved': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                      'note': 'valid when the dominant layer is a level-0 layer (64 -> 32 on the bench workload)'},
         'launches': best['launches'], 'avg_us': round(avg_us, 2),
         'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
         'all_instantiations': {'launches': total['launches'],
@@ -123,7 +130,7 @@ def measure_mfma(net, bucket, opt, dv, df, steps=3):
         train_step(net, bucket, opt, dv, df, collective=False)
     torch.cuda.synchronize()
     out = {'bound': 'mfma', 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'pmc': 'profiles/r01_pmc_gemm_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32; tools/pmc_mfma.py)'}
+           'pmc': 'profiles/r01_pmc_gemm_mfma.json (round-1 counters of these kernels: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32; tools/pmc_mfma.py)'}
     for name, tag in (('gemm_nn', 1), ('gemm_tn', 2)):
         n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'prof_collect')
