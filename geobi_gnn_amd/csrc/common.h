@@ -105,6 +105,11 @@ int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, 
                    const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
                    const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
                    hipStream_t s);
+bool feast_rowpass_fused_supported(int Cin, int Cb);
+int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
+                        const int* rowptr, const int* col, int N, int LC, const float* ul, const float* gout,
+                        const float* out_act, float slope, int Cout, const float* Wf, int Kp, float* g_out, float* dl,
+                        float* dpn, float* dcs, int ld_dcs, hipStream_t s);
 // packed-weight buffer layout: [Wf | W' | Bf (fused forward) | Bdx (fused dx)]
 static inline size_t feast_wpack_plain_floats(int Cin, int Cout) {
   return (size_t)((GEOBI_H * Cin + 3) / 4 * 4) * Cout + (size_t)(GEOBI_H * Cout + 2 * GEOBI_HP) * Cin;

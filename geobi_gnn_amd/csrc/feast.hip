@@ -13,6 +13,8 @@
 //   dz = g W_packed^T;  row pass over targets: s_ijh = dz_i[h,:].x_j, softmax backward -> dl_ij;
 //   column pass over sources j: r_j[h,:] = sum_i q_ijh/deg_i g_i  (same gather kernel, transposed CSR);
 //   dx = [r | dp] [lin.weight ; u.weight];  dW = z^T g;  du = dp^T x;  dc, dbias column sums.
+#include <cstdlib>
+
 #include "common.h"
 #include "feast_dev.h"
 
@@ -204,26 +206,6 @@ __global__ __launch_bounds__(256) void feast_aggregate_kernel(
 }
 
 // --------------------------------------------------------------------- backward row pass
-// All-reduce over the G consecutive lanes of a group with DPP lane permutes (one v_add with a DPP
-// source modifier per step, no LDS round trip as ds_bpermute/__shfl would take):
-//   xor 1 / xor 2 inside a quad (quad_perm), quad <-> quad inside 8 lanes (row_half_mirror),
-//   8 <-> 8 inside a 16-lane DPP row (row_mirror); only G = 32 needs one cross-row step.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-  return v + __int_as_float(t);
-}
-
-template <int G>
-__device__ __forceinline__ float group_allreduce(float v) {
-  v = dpp_add<0xB1>(v);                              // quad_perm [1,0,3,2]
-  if constexpr (G >= 4) v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
-  if constexpr (G >= 8) v = dpp_add<0x141>(v);       // row_half_mirror
-  if constexpr (G >= 16) v = dpp_add<0x140>(v);      // row_mirror
-  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64); // across the two 16-lane rows of the group
-  return v;
-}
-
 // For every target i (group of G lanes holding dz_i): per in-edge recompute q, form
 // s_h = dz_i[h,:].x_j, softmax backward dl_h = q_h (s_h - sum q s) / deg_i, write dl per edge
 // and the per-node sums:  dpn_i = sum_j dl_ij  (what flows to -p_i),  dcs_i = dpn_i + dl_self.
@@ -757,17 +739,37 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   const float* xb_ = xb ? xb : xa;
   const int Ca_ = Cb ? Ca : Cin;
 
-  // 1. gradient through the fused leaky-relu
+  const int LC = edge_logit_channels(Cin, Cb);
+  // Fused forward (z == NULL): the aggregated rows were never written
+  const bool fused = z == nullptr;
+  // [dp | dcs]: the tail columns of r' (unfused dx GEMM) or a compact [N, 24] array (fused dx kernel)
+  float* dpd = fused ? b.dpd : b.rp + H * Cout;
+  const int ld_dpd = fused ? 2 * HP : ldr;
+  // packed Wf [Kp, Cout] for dz = g Wf^T
+  const float* wf = wf_saved;
+  if (wf == nullptr) {     // not kept from the forward: repack
+    pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
+    GEOBI_LAUNCH_OK();
+    wf = b.wf;
+  }
+  // One kernel for the first half of the backward when the layer reads <= 64 channels (GEOBI_ROWPASS_FUSED=0: A/B):
+  // g, dz (LDS only), row pass.  Otherwise three: leaky-relu backward, dz GEMM (dz [N, 9 Cin] through HBM), row pass.
+  static const bool rp_fused_on = [] { const char* f = getenv("GEOBI_ROWPASS_FUSED"); return !f || atoi(f) != 0; }();
+  const bool rp_fused = fused && rp_fused_on && feast_rowpass_fused_supported(Cin, Cb);
   const float* g = gout;
-  if (slope != 1.0f) {
+  if (slope != 1.0f) g = b.g;
+  if (rp_fused) {
+    prof_begin(PROF_ROWPASS, s, 0.0, Cin);
+    int rcf = feast_rowpass_fused(xa, xb_, Ca_, Cin, p, cvec, rowptr_in, col_in, (int)N, LC, u_w, gout,
+                                  slope != 1.0f ? out : nullptr, slope, Cout, wf, Kp, b.g, b.dl, b.dpn, dpd + HP, ld_dpd, s);
+    prof_end(PROF_ROWPASS, s);
+    GEOBI_TRY(rcf);
+  } else if (slope != 1.0f) {
+    // 1. gradient through the fused leaky-relu
     lrelu_bwd_kernel<<<cdiv(N * Cout, 256), 256, 0, s>>>(gout, out, slope, N * Cout, b.g);
     GEOBI_LAUNCH_OK();
-    g = b.g;
   }
-  const int LC = edge_logit_channels(Cin, Cb);
-  // Fused forward (z == NULL): the aggregated rows were never written; recompute them for dW = z^T g
-  const bool fused = z == nullptr;
-  // Fused + input gradient wanted: every weight gradient comes from ONE product [x | 1]^T r' on the rows r' the dx
+  // Fused + input gradient wanted: every weight gradient comes from ONE product x^T r' on the rows r' the dx
   // kernel forms anyway (dW[h,k,o] = sum_j x_j[k] r_j[h,o]): no z needed.  Without dx (first layer of the vertex
   // branch) z is recomputed by the aggregation kernel for dW = z^T g.
   const bool rform = fused && dxa != nullptr;
@@ -782,26 +784,20 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     ow.mode = TN_LIN_UNPACK; ow.C = dlin_w; ow.C2 = dbias; ow.Cin = Cin; ow.Cout = Cout; ow.accumulate = accumulate;
     GEOBI_TRY(gemm_tn(z, Kp, g, Cout, N, Kp + 1, Cout, Kp, -1, ow, b.tn_ws, b.tn_bytes, fk.side ? fk.side : s));
   }
-  // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
-  const float* wf = wf_saved;
-  if (wf == nullptr) {     // not kept from the forward: repack
-    pack_wf_kernel<<<cdiv((int64_t)Kp * Cout, 256), 256, 0, s>>>(lin_w, Cin, Cout, Kp, b.wf);
-    GEOBI_LAUNCH_OK();
-    wf = b.wf;
+  int rc = 0;
+  if (!rp_fused) {
+    // 2. dz = g Wf^T   ([N, Cout] x [Cout, Kp]; Wf is [Kp, Cout] row-major = B transposed)
+    GemmEpilogue ep0;
+    ep0.ws = b.gemm_ws;
+    ep0.ws_bytes = b.gemm_bytes;
+    GEOBI_TRY(gemm_nn(g, Cout, wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
+    // 3. row pass: per-edge softmax backward
+    prof_begin(PROF_ROWPASS, s, 0.0, Cin);
+    rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn, dpd + HP, ld_dpd, LC,
+                        u_w, s);
+    prof_end(PROF_ROWPASS, s);
+    GEOBI_TRY(rc);
   }
-  GemmEpilogue ep0;
-  ep0.ws = b.gemm_ws;
-  ep0.ws_bytes = b.gemm_bytes;
-  GEOBI_TRY(gemm_nn(g, Cout, wf, Cout, 1, b.dz, Kp, (int)N, Kp, Cout, ep0, s));
-  // 3. row pass: per-edge softmax backward
-  prof_begin(PROF_ROWPASS, s, 0.0, Cin);
-  // [dp | dcs]: the tail columns of r' (unfused dx GEMM) or a compact [N, 24] array (fused dx kernel)
-  float* dpd = fused ? b.dpd : b.rp + H * Cout;
-  const int ld_dpd = fused ? 2 * HP : ldr;
-  int rc = launch_rowpass(Cin, xa, xb_, Ca_, p, cvec, rowptr_in, col_in, b.dz, Kp, (int)N, b.dl, b.dpn,
-                          dpd + HP, ld_dpd, LC, u_w, s);
-  prof_end(PROF_ROWPASS, s);
-  GEOBI_TRY(rc);
   // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
   feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, dpd, ld_dpd, 0);
   GEOBI_LAUNCH_OK();

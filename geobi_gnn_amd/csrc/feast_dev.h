@@ -114,5 +114,26 @@ __device__ __forceinline__ void edge_logits(const float (&d)[LC], const float* s
 }
 
 
+// All-reduce over the G consecutive lanes of a group with DPP lane permutes (one v_add with a DPP
+// source modifier per step, no LDS round trip as ds_bpermute/__shfl would take):
+//   xor 1 / xor 2 inside a quad (quad_perm), quad <-> quad inside 8 lanes (row_half_mirror),
+//   8 <-> 8 inside a 16-lane DPP row (row_mirror); only G = 32 needs one cross-row step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(t);
+}
+
+template <int G>
+__device__ __forceinline__ float group_allreduce(float v) {
+  v = dpp_add<0xB1>(v);                              // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v = dpp_add<0x141>(v);       // row_half_mirror
+  if constexpr (G >= 16) v = dpp_add<0x140>(v);      // row_mirror
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64); // across the two 16-lane rows of the group
+  return v;
+}
+
+
 }  // namespace feast_dev
 }  // namespace geobi

@@ -376,6 +376,218 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward, first half, fused:  g = d(leaky-relu) gout,  dz = g Wf^T  (MFMA, into an LDS tile -- dz [N, 9 Cin] never
+// reaches HBM),  then the row pass over the tile's 32 target nodes: per in-edge recompute q, s_h = dz_i[h,:] . x_j,
+// softmax backward dl_h = q_h (s_h - sum q s) / deg_i  ->  dl [E, 12] and the per-node sums dpn (what flows to -p_i)
+// and dcs (dpn + the self edge's share).  The mirror image of the forward kernel: matrix phase first, gather second;
+// the node's dz row is read into registers and its LDS row then serves as the parking slots of its edges.
+// Shapes: C = Cin <= 64 (one chunk); Cout in {32, 64, 128} (the reduction length of the matrix phase).
+template <int C, int LC, int COUT>
+__global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
+    const float* __restrict__ ul, const float* __restrict__ gout, const float* __restrict__ out_act, float slope,
+    const float* __restrict__ Wf, int Kp, float* __restrict__ g_out, float* __restrict__ dl, float* __restrict__ dpn,
+    float* __restrict__ dcs, int ld_dcs) {
+  constexpr int VEC = C >= 16 ? C / 16 : 1;
+  constexpr int ACTIVE = C >= 16 ? 16 : C;
+  constexpr int K = H * C;
+  constexpr int NCT = (K + 31) / 32;             // 32-column tiles of dz
+  constexpr int LDZ = NCT * 32 > G * HP ? NCT * 32 : G * HP;   // tile row stride (not an MFMA operand: no padding), wide
+                                                               // enough for the 16 parking slots of the node
+  constexpr int GL = COUT + 4;                   // g tile row stride: conflict-free ds_read_b128 of the A operand
+  static_assert(C <= 64 && G * HP <= LDZ, "one chunk; the parking slots fit the node's own row");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_g = smem;                             // [32][GL]
+  float* s_z = smem + TN * GL;                   // [32][LDZ]
+  float* s_u = s_z + TN * LDZ;
+  if constexpr (LC > 0) stage_u<LC>(ul, s_u);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = xcd_block(blockIdx.x, gridDim.x);
+  if (tile * TN >= N) return;
+
+  // ---- g tile: gradient through the fused leaky-relu, kept for the MFMAs and written out for the dx kernel
+  {
+    constexpr int Q = COUT / 4;
+    for (int i = threadIdx.x; i < TN * Q; i += 512) {
+      const int r = i / Q, c4 = (i - r * Q) * 4;
+      const int gn = tile * TN + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gn < N) {
+        v = *reinterpret_cast<const float4*>(gout + (size_t)gn * COUT + c4);
+        if (out_act != nullptr) {
+          const float4 o = *reinterpret_cast<const float4*>(out_act + (size_t)gn * COUT + c4);
+          v.x = o.x > 0.f ? v.x : v.x * slope; v.y = o.y > 0.f ? v.y : v.y * slope;
+          v.z = o.z > 0.f ? v.z : v.z * slope; v.w = o.w > 0.f ? v.w : v.w * slope;
+          *reinterpret_cast<float4*>(g_out + (size_t)gn * COUT + c4) = v;
+        }
+      }
+      *reinterpret_cast<float4*>(s_g + r * GL + c4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- matrix phase: dz[32, K] = g[32, COUT] Wf^T; wave w owns column tiles w, w + 8, w + 16
+  {
+    const int hf = lane >> 5, l31 = lane & 31;
+    constexpr int NKB = COUT / 8;
+    const float* arow = s_g + l31 * GL + 4 * hf;
+    for (int ct = wave; ct < NCT; ct += NW) {
+      const int krow = min(ct * 32 + l31, Kp - 1);                 // rows past K: clamped, their columns are never read
+      const float* brow = Wf + (size_t)krow * COUT + 4 * hf;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      constexpr int HB = NKB > 8 ? 8 : NKB;                        // k-blocks per batch of weight loads
+#pragma unroll
+      for (int b0 = 0; b0 < NKB; b0 += HB) {
+        float4 w[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) w[u] = *reinterpret_cast<const float4*>(brow + 8 * (b0 + u));
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[u].w, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[r];
+    }
+  }
+  __syncthreads();
+
+  // ---- row pass: 16 lanes per target node, a wave owns 4 nodes
+  const int g = lane / G, k = lane % G;
+  const int nl = wave * NPW + g;
+  const int node = tile * TN + nl;
+  const bool valid = node < N;
+  const bool act = k < ACTIVE;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int re = valid ? rowptr[ns + 1] : rs;
+  float* zrow = s_z + nl * LDZ;
+  const int c0 = act ? k * VEC : 0;
+  const float* fbase;
+  int fstride;
+  if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
+
+  float dzr[H][VEC];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dzr[h][v] = 0.f;
+    if (act) load_piece<VEC>(zrow + h * C + c0, dzr[h]);
+  }
+  wave_lds_sync();                               // every lane holds its slice: the row now serves as parking slots
+  float(*slot)[HP] = reinterpret_cast<float(*)[HP]>(zrow);
+
+  float cc[H], qs[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
+  softmax9(qs);
+  float xc[LC > 0 ? LC : 1];
+  if constexpr (LC > 0) load_row<LC>(xa + (size_t)ns * LC, xc);
+  const float invd = 1.0f / (float)(re - rs + 1);
+  float dsum[H], dself[H];
+  {
+    float xs[VEC];
+    load_piece<VEC>(fbase + (size_t)ns * fstride, xs);
+    float sv[H];
+    float tq = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float a = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xs[v], a);
+      sv[h] = group_allreduce<G>(act ? a : 0.f);
+      tq = fmaf(qs[h], sv[h], tq);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      dself[h] = qs[h] * (sv[h] - tq) * invd;
+      dsum[h] = 0.f;
+    }
+  }
+  for (int base = rs; base < re; base += G) {
+    {
+      const int e = base + k;
+      float q[H];
+      int j = ns;
+      if (e < re) {
+        j = col[e];
+        if constexpr (LC > 0) {
+          float d[LC];
+          load_row<LC>(xa + (size_t)j * LC, d);
+#pragma unroll
+          for (int i = 0; i < LC; ++i) d[i] -= xc[i];
+          edge_logits<LC>(d, s_u, cc, q);
+        } else {
+          float pc[H], pn[H];
+          const float* prow = p + (size_t)ns * HP;
+          asm volatile("" : "+v"(prow));
+          load_hp(prow, pc);
+          load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+          for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+        }
+        softmax9(q);
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = 0.f;
+      }
+      float4* dst = reinterpret_cast<float4*>(slot[k]);
+      dst[0] = make_float4(q[0], q[1], q[2], q[3]);
+      dst[1] = make_float4(q[4], q[5], q[6], q[7]);
+      dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
+    }
+    wave_lds_sync();
+    const int cnt = min(G, re - base);
+    for (int t = 0; t < cnt; ++t) {
+      const float4* sp = reinterpret_cast<const float4*>(slot[t]);
+      const float4 a0 = sp[0], b0 = sp[1], d0 = sp[2];
+      float xj[VEC];
+      load_piece<VEC>(fbase + (size_t)__float_as_int(d0.y) * fstride, xj);
+      const float q[H] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x};
+      float sv[H];
+      float tq = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xj[v], a);
+        sv[h] = group_allreduce<G>(act ? a : 0.f);
+        tq = fmaf(q[h], sv[h], tq);
+      }
+      float d[HP];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        d[h] = q[h] * (sv[h] - tq) * invd;
+        dsum[h] += d[h];
+      }
+      d[9] = d[10] = d[11] = 0.f;
+      float4* drow = reinterpret_cast<float4*>(dl + (size_t)(base + t) * HP);
+#pragma unroll
+      for (int c4 = 0; c4 < 3; ++c4)
+        if (k == c4) drow[c4] = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
+    }
+    wave_lds_sync();
+  }
+  if (!valid || k != 0) return;
+  float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
+  a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
+  a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
+  a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
+  float4* bq = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
+  bq[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
+  bq[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
+  bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
+}
+
 // Packed weights of the forward:  Bp[kb][half][col][s] = lin.weight[h * Cout + col, kin] for k = 8 kb + 4 half + s
 // = h * Cin + kin (zero for k >= 9 Cin or col >= Cout), NP = padded column count (multiple of 32).
 __global__ void pack_fused_fwd_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int KD, int NP,
@@ -489,6 +701,57 @@ extern "C" int geobi_debug_stamps(void* host_dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+namespace {
+template <int C, int LC, int COUT>
+int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
+                         const int* col, int N, const float* ul, const float* gout, const float* out_act, float slope,
+                         const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
+                         hipStream_t s) {
+  constexpr int NCT = (H * C + 31) / 32;
+  constexpr int LDZ = NCT * 32 > G * HP ? NCT * 32 : G * HP;
+  constexpr size_t lds = ((size_t)TN * (COUT + 4) + (size_t)TN * LDZ + (LC > 0 ? LC * HP : 0)) * sizeof(float);
+  static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  feast_rowpass_fused_kernel<C, LC, COUT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+      xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp, g_out, dl, dpn, dcs, ld_dcs);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+}  // namespace
+
+bool feast_rowpass_fused_supported(int Cin, int Cb) { return Cin <= 64 && (Cb == 0 || Cin >= 32); }
+
+// g (written to g_out when slope != 1), dl, dpn, dcs of one layer in one launch; LC: per-edge logit channels (0 / 6 / 12)
+int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
+                        const int* rowptr, const int* col, int N, int LC, const float* ul, const float* gout,
+                        const float* out_act, float slope, int Cout, const float* Wf, int Kp, float* g_out, float* dl,
+                        float* dpn, float* dcs, int ld_dcs, hipStream_t s) {
+#define GEOBI_RP_ARGS xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp, g_out, dl, dpn, dcs, ld_dcs, s
+#define GEOBI_RP_COUT(C_, L_)                                                            \
+  switch (Cout) {                                                                        \
+    case 32: return launch_rowpass_fused<C_, L_, 32>(GEOBI_RP_ARGS);                     \
+    case 64: return launch_rowpass_fused<C_, L_, 64>(GEOBI_RP_ARGS);                     \
+    case 128: return launch_rowpass_fused<C_, L_, 128>(GEOBI_RP_ARGS);                   \
+    default: return set_error("feast fused row pass: unsupported Cout=%d", Cout);        \
+  }
+  switch (Cin * 100 + LC) {
+    case 600: GEOBI_RP_COUT(6, 0)
+    case 606: GEOBI_RP_COUT(6, 6)
+    case 1200: GEOBI_RP_COUT(12, 0)
+    case 1212: GEOBI_RP_COUT(12, 12)
+    case 3200: GEOBI_RP_COUT(32, 0)
+    case 6400: GEOBI_RP_COUT(64, 0)
+    default: return set_error("feast fused row pass: unsupported Cin=%d (per-edge logit channels %d)", Cin, LC);
+  }
+#undef GEOBI_RP_COUT
+#undef GEOBI_RP_ARGS
+}
 
 int feast_fused_nt(int nout) { return nout <= 32 ? 1 : (nout <= 64 ? 2 : 4); }
 size_t feast_fused_fwd_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout); }
