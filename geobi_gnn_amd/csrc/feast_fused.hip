@@ -24,6 +24,7 @@
 //                    pre-activation output), transposed CSR, weights q_ij / deg_i; the tile gets 24 extra
 //                    columns [dp | dcs] read from `dpd`; output split into (dxa | dxb) for split inputs.
 #include "common.h"
+#include <type_traits>
 #include "feast_dev.h"
 
 namespace geobi {
@@ -72,6 +73,45 @@ constexpr int fused_lds_floats() { return Shape<C, MODE>::TILE_FLOATS + Shape<C,
 constexpr int fused_k(int C, int MODE) { return MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP; }
 
 // One lane's share of a row: PV floats per piece
+
+// acc += sum_v  (lane OWNER's dz[v]) * x[v]  for the PV floats of one piece: the row broadcast rides on the FMA's first
+// operand (v_fmac_f32_dpp row_newbcast, gfx90a+), no separate move.  Every lane of the 16-lane row must be active: a
+// source lane EXEC has switched off does not deliver.  The leading s_nop covers the two wait states a DPP read needs
+// after a VALU write of the same register -- the compiler's hazard pass does not look inside the statement.
+template <int OWNER, int PV>
+__device__ __forceinline__ void fmac_bcast(float& acc, const float* dz, const float* x) {
+  static_assert(OWNER >= 0 && OWNER < 16 && (PV == 4 || PV == 2), "a DPP row has 16 lanes");
+#define GEOBI_FB(M)                                                                                                   \
+  if constexpr (OWNER == M) {                                                                                         \
+    if constexpr (PV == 4)                                                                                            \
+      asm("s_nop 1\n\t"                                                                                               \
+          "v_fmac_f32_dpp %0, %1, %5 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %2, %6 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %3, %7 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %4, %8 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
+          : "+v"(acc)                                                                                                 \
+          : "v"(dz[0]), "v"(dz[1]), "v"(dz[2]), "v"(dz[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));              \
+    else                                                                                                              \
+      asm("s_nop 1\n\t"                                                                                               \
+          "v_fmac_f32_dpp %0, %1, %3 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %2, %4 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
+          : "+v"(acc)                                                                                                 \
+          : "v"(dz[0]), "v"(dz[1]), "v"(x[0]), "v"(x[1]));                                                            \
+  }
+  GEOBI_FB(0) GEOBI_FB(1) GEOBI_FB(2) GEOBI_FB(3) GEOBI_FB(4) GEOBI_FB(5) GEOBI_FB(6) GEOBI_FB(7)
+  GEOBI_FB(8) GEOBI_FB(9) GEOBI_FB(10) GEOBI_FB(11) GEOBI_FB(12) GEOBI_FB(13) GEOBI_FB(14) GEOBI_FB(15)
+#undef GEOBI_FB
+}
+
+// f(integral_constant<int, I>) for I in [0, N): loop indices that must be constants (DPP controls, register slots)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int PV>
 __device__ __forceinline__ void load_piece(const float* __restrict__ ptr, float* v) {
   if constexpr (PV == 4) {
@@ -95,9 +135,12 @@ __device__ __forceinline__ void store_piece(float* ptr, const float* v) {
 // Diagnostic build only (tools/build_variant.sh ... -DGEOBI_FUSED_STAMPS): shader-clock stamps of wave 0 of each
 // workgroup at the phase boundaries, written to a buffer nothing else reads.
 __device__ unsigned long long g_stamps[16384][8];
+__device__ unsigned long long g_stamps_bwd[16384][8];       // the fused backward row pass keeps its own set
 #define GEOBI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GEOBI_STAMP_BWD(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps_bwd[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GEOBI_STAMP(i) do { } while (0)
+#define GEOBI_STAMP_BWD(i) do { } while (0)
 #endif
 
 template <int C, int MODE, int LC, int NT>
@@ -390,14 +433,11 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
     const float* __restrict__ ul, const float* __restrict__ gout, const float* __restrict__ out_act, float slope,
     const float* __restrict__ Wf, int Kp, float* __restrict__ g_out, float* __restrict__ dl, float* __restrict__ dpn,
     float* __restrict__ dcs, int ld_dcs) {
-  constexpr int VEC = C >= 16 ? C / 16 : 1;
-  constexpr int ACTIVE = C >= 16 ? 16 : C;
   constexpr int K = H * C;
   constexpr int NCT = (K + 31) / 32;             // 32-column tiles of dz
-  constexpr int LDZ = NCT * 32 > G * HP ? NCT * 32 : G * HP;   // tile row stride (not an MFMA operand: no padding), wide
-                                                               // enough for the 16 parking slots of the node
+  constexpr int LDZ = NCT * 32 + 4;              // + 4: the four node groups of a wave read distinct bank quads
   constexpr int GL = COUT + 4;                   // g tile row stride: conflict-free ds_read_b128 of the A operand
-  static_assert(C <= 64 && G * HP <= LDZ, "one chunk; the parking slots fit the node's own row");
+  static_assert(C <= 64, "one chunk");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_g = smem;                             // [32][GL]
   float* s_z = smem + TN * GL;                   // [32][LDZ]
@@ -407,6 +447,7 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = xcd_block(blockIdx.x, gridDim.x);
   if (tile * TN >= N) return;
+  GEOBI_STAMP_BWD(0);
 
   // ---- g tile: gradient through the fused leaky-relu, kept for the MFMAs and written out for the dx kernel
   {
@@ -428,63 +469,94 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
     }
   }
   __syncthreads();
+  GEOBI_STAMP_BWD(1);
 
   // ---- matrix phase: dz[32, K] = g[32, COUT] Wf^T; wave w owns column tiles w, w + 8, w + 16
+  // The weights of all of a wave's tiles are requested together, four k-blocks at a time: one exposed load latency
+  // per batch instead of one per tile.
   {
     const int hf = lane >> 5, l31 = lane & 31;
     constexpr int NKB = COUT / 8;
+    constexpr int MAXT = (NCT + NW - 1) / NW;                      // column tiles per wave (<= 3)
+    constexpr int HB = 4;                                          // k-blocks per batch of weight loads
+    static_assert(NKB % HB == 0, "whole batches");
     const float* arow = s_g + l31 * GL + 4 * hf;
-    for (int ct = wave; ct < NCT; ct += NW) {
+    const float* brow[MAXT];
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int ct = wave + t * NW;
       const int krow = min(ct * 32 + l31, Kp - 1);                 // rows past K: clamped, their columns are never read
-      const float* brow = Wf + (size_t)krow * COUT + 4 * hf;
-      f32x16 acc;
+      brow[t] = Wf + (size_t)krow * COUT + 4 * hf;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      constexpr int HB = NKB > 8 ? 8 : NKB;                        // k-blocks per batch of weight loads
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
 #pragma unroll
-      for (int b0 = 0; b0 < NKB; b0 += HB) {
-        float4 w[HB];
+    for (int b0 = 0; b0 < NKB; b0 += HB) {
+      float4 w[MAXT][HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) w[u] = *reinterpret_cast<const float4*>(brow + 8 * (b0 + u));
+      for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-        for (int u = 0; u < HB; ++u) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[u].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[u].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[u].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[u].w, acc, 0, 0, 0);
+        for (int u = 0; u < HB; ++u) w[t][u] = *reinterpret_cast<const float4*>(brow[t] + 8 * (b0 + u));
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t][u].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t][u].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t][u].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t][u].w, acc[t], 0, 0, 0);
         }
       }
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[r];
+    for (int t = 0; t < MAXT; ++t) {
+      const int ct = wave + t * NW;
+      if (ct < NCT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[t][r];
+      }
     }
   }
+  GEOBI_STAMP_BWD(2);
   __syncthreads();
+  GEOBI_STAMP_BWD(3);
 
-  // ---- row pass: 16 lanes per target node, a wave owns 4 nodes
+  // ---- row pass, lane = edge: the 16 lanes of a node's group each take one in-edge (plus one pseudo-edge for the self
+  // loop) and form all nine dot products s_h = dz_i[h,:] . x_j on their own -- the neighbour row is the lane's private
+  // read (C/4 16-B loads in flight at once), the node's dz row comes from the LDS tile as broadcast reads -- so the
+  // softmax backward needs no cross-lane step at all, dl rows leave as 48 contiguous bytes per lane, and only the
+  // per-node sums are reduced over the group once per 16 edges.
   const int g = lane / G, k = lane % G;
   const int nl = wave * NPW + g;
   const int node = tile * TN + nl;
   const bool valid = node < N;
-  const bool act = k < ACTIVE;
   const int ns = valid ? node : N - 1;
   const int rs = rowptr[ns];
-  const int re = valid ? rowptr[ns + 1] : rs;
-  float* zrow = s_z + nl * LDZ;
-  const int c0 = act ? k * VEC : 0;
-  const float* fbase;
-  int fstride;
-  if (c0 < Ca) { fbase = xa + c0; fstride = Ca; } else { fbase = xb + (c0 - Ca); fstride = C - Ca; }
-
-  float dzr[H][VEC];
+  const int deg = valid ? rowptr[ns + 1] - rs : -1;          // items = deg real edges + the self loop; none if invalid
+  // The node's dz row [9][C], one piece per lane and slot (piece p -> slot p / 16, lane p % 16): read from the tile
+  // once; the dot products fetch each piece from its owner lane with a row broadcast (DPP), not from LDS again --
+  // 16 lanes re-reading the same 144 pieces per edge chunk made the row pass LDS-bandwidth bound.
+  constexpr int VW = (C % 4 == 0) ? 4 : 2;                   // floats per piece
+  constexpr int NQ = C / VW;                                 // pieces per head
+  constexpr int NPIECE = H * NQ, NSLOT = (NPIECE + G - 1) / G;
+  float dzr[NSLOT][VW];
+  {
+    const float* zrow = s_z + nl * LDZ;
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      const int pidx = sl * G + k;
+      if (pidx < NPIECE) load_piece<VW>(zrow + pidx * VW, dzr[sl]);
+      else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) dzr[h][v] = 0.f;
-    if (act) load_piece<VEC>(zrow + h * C + c0, dzr[h]);
+        for (int v = 0; v < VW; ++v) dzr[sl][v] = 0.f;
+      }
+    }
   }
-  wave_lds_sync();                               // every lane holds its slice: the row now serves as parking slots
-  float(*slot)[HP] = reinterpret_cast<float(*)[HP]>(zrow);
+  const int Cb = C - Ca;
+  constexpr int XB = NQ % 4 == 0 ? 4 : NQ;                   // row pieces per batch (16 channels, or the whole short row)
+  static_assert(NQ % XB == 0 && XB <= 4, "whole batches");
 
   float cc[H], qs[H];
 #pragma unroll
@@ -492,34 +564,20 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
   softmax9(qs);
   float xc[LC > 0 ? LC : 1];
   if constexpr (LC > 0) load_row<LC>(xa + (size_t)ns * LC, xc);
-  const float invd = 1.0f / (float)(re - rs + 1);
+  const float invd = 1.0f / (float)(deg + 1);
   float dsum[H], dself[H];
-  {
-    float xs[VEC];
-    load_piece<VEC>(fbase + (size_t)ns * fstride, xs);
-    float sv[H];
-    float tq = 0.f;
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      float a = 0.f;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xs[v], a);
-      sv[h] = group_allreduce<G>(act ? a : 0.f);
-      tq = fmaf(qs[h], sv[h], tq);
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      dself[h] = qs[h] * (sv[h] - tq) * invd;
-      dsum[h] = 0.f;
-    }
-  }
-  for (int base = rs; base < re; base += G) {
-    {
-      const int e = base + k;
+  for (int h = 0; h < H; ++h) { dsum[h] = 0.f; dself[h] = 0.f; }
+
+  for (int base = 0; base <= deg; base += G) {
+    const int idx = base + k;
+    const bool real = idx < deg, self = idx == deg;
+    {  // every lane of the group runs the dot products (a row broadcast reads 0 from a lane EXEC has switched off);
+       // lanes past the node's items work on the node's own row and drop the result
+      const int e = rs + idx;
+      const int j = real ? col[e] : ns;
       float q[H];
-      int j = ns;
-      if (e < re) {
-        j = col[e];
+      if (real) {
         if constexpr (LC > 0) {
           float d[LC];
           load_row<LC>(xa + (size_t)j * LC, d);
@@ -528,9 +586,7 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
           edge_logits<LC>(d, s_u, cc, q);
         } else {
           float pc[H], pn[H];
-          const float* prow = p + (size_t)ns * HP;
-          asm volatile("" : "+v"(prow));
-          load_hp(prow, pc);
+          load_hp(p + (size_t)ns * HP, pc);
           load_hp(p + (size_t)j * HP, pn);
 #pragma unroll
           for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
@@ -538,45 +594,58 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
         softmax9(q);
       } else {
 #pragma unroll
-        for (int h = 0; h < H; ++h) q[h] = 0.f;
+        for (int h = 0; h < H; ++h) q[h] = qs[h];
       }
-      float4* dst = reinterpret_cast<float4*>(slot[k]);
-      dst[0] = make_float4(q[0], q[1], q[2], q[3]);
-      dst[1] = make_float4(q[4], q[5], q[6], q[7]);
-      dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
-    }
-    wave_lds_sync();
-    const int cnt = min(G, re - base);
-    for (int t = 0; t < cnt; ++t) {
-      const float4* sp = reinterpret_cast<const float4*>(slot[t]);
-      const float4 a0 = sp[0], b0 = sp[1], d0 = sp[2];
-      float xj[VEC];
-      load_piece<VEC>(fbase + (size_t)__float_as_int(d0.y) * fstride, xj);
-      const float q[H] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x};
+      // nine dot products over the row, channels in ascending order; the row arrives in batches of XB pieces, every
+      // piece of a batch requested before any is used
       float sv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) sv[h] = 0.f;
+      const float* ra = xa + (size_t)j * Ca;
+      const float* rb = xb + (size_t)j * Cb - Ca;                          // indexed by the channel of the whole row
+      static_for<0, NQ / XB>([&](auto bi) {
+        constexpr int q0 = decltype(bi)::value * XB;
+        const float* src = q0 * VW < Ca ? ra : rb;                          // a batch never straddles the two inputs
+        float xj[XB][VW];
+#pragma unroll
+        for (int qd = 0; qd < XB; ++qd) load_piece<VW>(src + (q0 + qd) * VW, xj[qd]);
+        static_for<0, XB>([&](auto qi) {
+          constexpr int qd = decltype(qi)::value;
+          static_for<0, H>([&](auto hi) {
+            constexpr int h = decltype(hi)::value;
+            constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
+            fmac_bcast<owner, VW>(sv[h], dzr[sl], xj[qd]);
+          });
+        });
+      });
       float tq = 0.f;
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        float a = 0.f;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) a = fmaf(dzr[h][v], xj[v], a);
-        sv[h] = group_allreduce<G>(act ? a : 0.f);
-        tq = fmaf(q[h], sv[h], tq);
-      }
+      for (int h = 0; h < H; ++h) tq = fmaf(q[h], sv[h], tq);
       float d[HP];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        d[h] = q[h] * (sv[h] - tq) * invd;
-        dsum[h] += d[h];
-      }
+      for (int h = 0; h < H; ++h) d[h] = q[h] * (sv[h] - tq) * invd;
       d[9] = d[10] = d[11] = 0.f;
-      float4* drow = reinterpret_cast<float4*>(dl + (size_t)(base + t) * HP);
+      if (real) {
+        float4* drow = reinterpret_cast<float4*>(dl + (size_t)e * HP);
+        drow[0] = make_float4(d[0], d[1], d[2], d[3]);
+        drow[1] = make_float4(d[4], d[5], d[6], d[7]);
+        drow[2] = make_float4(d[8], 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int c4 = 0; c4 < 3; ++c4)
-        if (k == c4) drow[c4] = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
+        for (int h = 0; h < H; ++h) dsum[h] += d[h];
+      } else if (self) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) dself[h] = d[h];
+      }
     }
-    wave_lds_sync();
   }
+  GEOBI_STAMP_BWD(4);
+  // per-node sums over the group (fixed butterfly: deterministic)
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dsum[h] = group_allreduce<G>(dsum[h]);
+    dself[h] = group_allreduce<G>(dself[h]);
+  }
+  GEOBI_STAMP_BWD(5);
   if (!valid || k != 0) return;
   float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
   a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
@@ -700,6 +769,9 @@ int launch_nt(int NT, const float* xa, const float* xb, int Ca, const float* p, 
 extern "C" int geobi_debug_stamps(void* host_dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
+extern "C" int geobi_debug_stamps_bwd(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps_bwd), bytes, 0, hipMemcpyDeviceToHost);
+}
 #endif
 
 namespace {
@@ -709,7 +781,7 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
                          const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
                          hipStream_t s) {
   constexpr int NCT = (H * C + 31) / 32;
-  constexpr int LDZ = NCT * 32 > G * HP ? NCT * 32 : G * HP;
+  constexpr int LDZ = NCT * 32 + 4;
   constexpr size_t lds = ((size_t)TN * (COUT + 4) + (size_t)TN * LDZ + (LC > 0 ? LC * HP : 0)) * sizeof(float);
   static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
   static bool attr_set = false;
@@ -725,7 +797,10 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
 }
 }  // namespace
 
-bool feast_rowpass_fused_supported(int Cin, int Cb) { return Cin <= 64 && (Cb == 0 || Cin >= 32); }
+// split inputs: the row is read in batches of 16 channels, so the first part must end on such a boundary
+bool feast_rowpass_fused_supported(int Cin, int Cb) {
+  return Cin <= 64 && (Cb == 0 || (Cin >= 32 && (Cin - Cb) % 16 == 0));
+}
 
 // g (written to g_out when slope != 1), dl, dpn, dcs of one layer in one launch; LC: per-edge logit channels (0 / 6 / 12)
 int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
