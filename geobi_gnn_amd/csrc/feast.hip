@@ -564,6 +564,26 @@ int launch_aggregate(int C, const float* xa, const float* xb, int Ca, const floa
   return 0;
 }
 
+// The row pass with lane = edge (feast_dev.h rowpass_edge_node), dz rows read from HBM: the standalone form of what
+// the fused backward kernel runs on its LDS tile; used where dz was formed by the plain GEMM (128-channel layers,
+// split inputs the fused kernel does not take, GEOBI_FUSED=0).  Four waves x four nodes per block.
+template <int C, int LC>
+__global__ __launch_bounds__(256, 4) void feast_rowpass_edge_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ dz, int ldz, int N, float* __restrict__ dl, float* __restrict__ dpn,
+    float* __restrict__ dcs, int ld_dcs, const float* __restrict__ ul) {
+  __shared__ __attribute__((aligned(16))) float s_u[LC > 0 ? LC * HP : 4];
+  if constexpr (LC > 0) stage_u<LC>(ul, s_u);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int node0 = (xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * 4;
+  if (node0 >= N) return;
+  const int node = node0 + lane / 16;
+  const int zn = node < N ? node : N - 1;
+  rowpass_edge_node<C, LC>(dz + (size_t)zn * ldz, xa, xb, Ca, p, cvec, s_u, rowptr, col, N, node,
+                                             lane % 16, dl, dpn, dcs, ld_dcs);
+}
+
 int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
                    const int* rowptr, const int* col, const float* dz, int ldz, int N, float* dl, float* dpn,
                    float* dcs, int ld_dcs, int LC, const float* ul, hipStream_t s) {
@@ -573,6 +593,25 @@ int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float*
     feast_rowpass_kernel<C_, V_, L_><<<xcd_grid(cdiv(N, 4 * NPW_)), 256, 0, s>>>(                               \
         xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, N, dl, dpn, dcs, ld_dcs, ul);                              \
   } while (0)
+  // lane = edge form unless the first input part of a split row ends off a 16-channel batch boundary; the per-edge
+  // logit layers (LC > 0: level 0, normally inside the fused kernel) keep the older form here
+  static const bool edge_form = [] { const char* f = getenv("GEOBI_ROWPASS_EDGE"); return !f || atoi(f) != 0; }();   // A/B knob
+  if (edge_form && LC == 0 && (Ca >= C || (C >= 32 && Ca % 16 == 0))) {
+#define GEOBI_ROWE(C_, L_)                                                                                    \
+  feast_rowpass_edge_kernel<C_, L_><<<xcd_grid(cdiv(N, 16)), 256, 0, s>>>(xa, xb, Ca, p, cvec, rowptr, col, dz, ldz, \
+                                                                        N, dl, dpn, dcs, ld_dcs, ul)
+    switch (C) {
+      case 6: GEOBI_ROWE(6, 0); break;
+      case 12: GEOBI_ROWE(12, 0); break;
+      case 32: GEOBI_ROWE(32, 0); break;
+      case 64: GEOBI_ROWE(64, 0); break;
+      case 128: GEOBI_ROWE(128, 0); break;
+      default: return set_error("feast: unsupported channel count %d", C);
+    }
+#undef GEOBI_ROWE
+    GEOBI_LAUNCH_OK();
+    return 0;
+  }
   switch (C) {
     case 6: if (LC) GEOBI_ROW(6, 3, 6); else GEOBI_ROW(6, 3, 0); break;
     case 12: if (LC) GEOBI_ROW(12, 3, 12); else GEOBI_ROW(12, 3, 0); break;

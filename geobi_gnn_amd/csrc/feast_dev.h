@@ -1,6 +1,7 @@
 // Device helpers shared by the FeaSt kernels (feast.hip, feast_fused.hip).  gfx950 only.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace geobi {
 namespace feast_dev {
@@ -132,6 +133,213 @@ __device__ __forceinline__ float group_allreduce(float v) {
   if constexpr (G >= 16) v = dpp_add<0x140>(v);      // row_mirror
   if constexpr (G >= 32) v += __shfl_xor(v, 16, 64); // across the two 16-lane rows of the group
   return v;
+}
+
+
+// One lane's share of a row: PV floats per piece
+
+template <int PV>
+__device__ __forceinline__ void load_piece(const float* __restrict__ ptr, float* v) {
+  if constexpr (PV == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(ptr);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (PV == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(ptr);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = ptr[0];
+  }
+}
+template <int PV>
+__device__ __forceinline__ void store_piece(float* ptr, const float* v) {
+  if constexpr (PV == 4) *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (PV == 2) *reinterpret_cast<float2*>(ptr) = make_float2(v[0], v[1]);
+  else ptr[0] = v[0];
+}
+
+// acc += sum_v  (lane OWNER's dz[v]) * x[v]  for the PV floats of one piece: the row broadcast rides on the FMA's first
+// operand (v_fmac_f32_dpp row_newbcast, gfx90a+), no separate move.  Every lane of the 16-lane row must be active: a
+// source lane EXEC has switched off does not deliver.  The leading s_nop covers the two wait states a DPP read needs
+// after a VALU write of the same register -- the compiler's hazard pass does not look inside the statement.
+template <int OWNER, int PV>
+__device__ __forceinline__ void fmac_bcast(float& acc, const float* dz, const float* x) {
+  static_assert(OWNER >= 0 && OWNER < 16 && (PV == 4 || PV == 2), "a DPP row has 16 lanes");
+#define GEOBI_FB(M)                                                                                                   \
+  if constexpr (OWNER == M) {                                                                                         \
+    if constexpr (PV == 4)                                                                                            \
+      asm("s_nop 1\n\t"                                                                                               \
+          "v_fmac_f32_dpp %0, %1, %5 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %2, %6 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %3, %7 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %4, %8 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
+          : "+v"(acc)                                                                                                 \
+          : "v"(dz[0]), "v"(dz[1]), "v"(dz[2]), "v"(dz[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));              \
+    else                                                                                                              \
+      asm("s_nop 1\n\t"                                                                                               \
+          "v_fmac_f32_dpp %0, %1, %3 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
+          "v_fmac_f32_dpp %0, %2, %4 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
+          : "+v"(acc)                                                                                                 \
+          : "v"(dz[0]), "v"(dz[1]), "v"(x[0]), "v"(x[1]));                                                            \
+  }
+  GEOBI_FB(0) GEOBI_FB(1) GEOBI_FB(2) GEOBI_FB(3) GEOBI_FB(4) GEOBI_FB(5) GEOBI_FB(6) GEOBI_FB(7)
+  GEOBI_FB(8) GEOBI_FB(9) GEOBI_FB(10) GEOBI_FB(11) GEOBI_FB(12) GEOBI_FB(13) GEOBI_FB(14) GEOBI_FB(15)
+#undef GEOBI_FB
+}
+
+// f(integral_constant<int, I>) for I in [0, N): loop indices that must be constants (DPP controls, register slots)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward row pass of one target node by its 16-lane group, lane = edge: each lane takes one in-edge (plus one
+// pseudo-edge for the self loop) and forms all nine dot products s_h = dz_i[h,:] . x_j on its own -- the neighbour
+// row is the lane's private read, the node's dz row is spread over the group (piece p -> slot p / 16, lane p % 16) and each piece reaches the FMAs by a row broadcast riding on the operand.  The softmax backward
+//   dl_h = q_h (s_h - sum q s) / (deg_i + 1)
+// then needs no cross-lane step, dl rows leave as 48 contiguous bytes per lane, and only the per-node sums
+// dpn (what flows to -p_i) and dcs (dpn + the self edge's share) are reduced over the group, once per node.
+// (The earlier form -- lanes = channel slices, nine 16-lane reductions per edge -- spent most of its instructions in
+// those reductions; re-reading the dz row from LDS per edge was LDS-bandwidth bound.)
+//   zrow: the node's dz row [9][C] (LDS or global, 16-B aligned).  At 128 channels the dz pieces are taken in two
+//   halves of 64 channels (the dot products add up over channels), so the neighbour row is still read once.
+// Every lane of the group runs the dot products: a row broadcast does not deliver from a lane EXEC has switched off.
+template <int C, int LC>
+__device__ __forceinline__ void rowpass_edge_node(
+    const float* zrow, const float* __restrict__ xa, const float* __restrict__ xb, int Ca,
+    const float* __restrict__ p, const float* __restrict__ cvec, const float* s_u, const int* __restrict__ rowptr,
+    const int* __restrict__ col, int N, int node, int k, float* __restrict__ dl, float* __restrict__ dpn,
+    float* __restrict__ dcs, int ld_dcs) {
+  constexpr int G = 16;
+  constexpr int VW = (C % 4 == 0) ? 4 : 2;                   // floats per piece
+  constexpr int CCH = C > 64 ? 64 : C;                       // channels whose dz pieces are in registers at once
+  constexpr int NCC = C / CCH;                               // channel chunks (2 at 128 channels)
+  constexpr int NQ = CCH / VW;                               // pieces per head and chunk
+  constexpr int XB = NQ % 4 == 0 ? 4 : NQ;                   // row pieces per batch (16 channels, or the whole short row)
+  constexpr int NPIECE = H * NQ, NSLOT = (NPIECE + G - 1) / G;
+  static_assert(NQ % XB == 0 && XB <= 4 && C % CCH == 0, "whole batches, whole channel chunks");
+  const bool valid = node < N;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int deg = valid ? rowptr[ns + 1] - rs : -1;          // items = deg real edges + the self loop; none if invalid
+  const int Cb = C - Ca;
+
+  float dzr[NSLOT][VW];
+  auto load_dz = [&](int c) {                                // piece pidx of chunk c = head pidx / NQ, piece pidx % NQ
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      const int pidx = sl * G + k;
+      if (pidx < NPIECE) load_piece<VW>(zrow + (pidx / NQ) * C + c * CCH + (pidx % NQ) * VW, dzr[sl]);
+      else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) dzr[sl][v] = 0.f;
+      }
+    }
+  };
+  if constexpr (NCC == 1) load_dz(0);
+
+  float cc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) cc[h] = cvec[h];
+  float xc[LC > 0 ? LC : 1];
+  if constexpr (LC > 0) load_row<LC>(xa + (size_t)ns * LC, xc);
+  const float invd = 1.0f / (float)(deg + 1);
+  // dsum: the lane's real edges.  The self loop is item `deg`, i.e. always in the node's LAST chunk: its share is
+  // picked from that iteration's d after the loop (d and self are dead across the dot products of later chunks,
+  // so they cost no registers there).
+  float dsum[H], d[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { dsum[h] = 0.f; d[h] = 0.f; }
+  bool self = false;
+
+  for (int base = 0; base <= deg; base += G) {
+    const int idx = base + k;
+    const bool real = idx < deg;
+    self = idx == deg;
+    const int e = rs + idx;
+    const int j = real ? col[e] : ns;                        // lanes past the node's items work on its own row
+    float q[H];
+    if (real) {
+      if constexpr (LC > 0) {
+        float d[LC];
+        load_row<LC>(xa + (size_t)j * LC, d);
+#pragma unroll
+        for (int i = 0; i < LC; ++i) d[i] -= xc[i];
+        edge_logits<LC>(d, s_u, cc, q);
+      } else {
+        float pc[H], pn[H];
+        load_hp(p + (size_t)ns * HP, pc);
+        load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+      }
+      softmax9(q);
+    } else {                                                 // the self loop: u (x_i - x_i) + c = c exactly
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = cc[h];
+      softmax9(q);
+    }
+    // nine dot products over the row, channels in ascending order; the row arrives in batches of XB pieces, every
+    // piece of a batch requested before any is used
+    float sv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) sv[h] = 0.f;
+    const float* ra = xa + (size_t)j * Ca;
+    const float* rb = xb + (size_t)j * Cb - Ca;              // indexed by the channel of the whole row
+    static_for<0, NCC>([&](auto ci) {
+      constexpr int c = decltype(ci)::value;
+      if constexpr (NCC > 1) load_dz(c);
+      static_for<0, NQ / XB>([&](auto bi) {
+        constexpr int q0 = decltype(bi)::value * XB;
+        constexpr int ch0 = c * CCH + q0 * VW;               // first channel of the batch
+        const float* src = ch0 < Ca ? ra : rb;               // a batch never straddles the two inputs
+        float xj[XB][VW];
+#pragma unroll
+        for (int qd = 0; qd < XB; ++qd) load_piece<VW>(src + ch0 + qd * VW, xj[qd]);
+        static_for<0, XB>([&](auto qi) {
+          constexpr int qd = decltype(qi)::value;
+          static_for<0, H>([&](auto hi) {
+            constexpr int h = decltype(hi)::value;
+            constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
+            fmac_bcast<owner, VW>(sv[h], dzr[sl], xj[qd]);
+          });
+        });
+      });
+    });
+    float tq = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) tq = fmaf(q[h], sv[h], tq);
+#pragma unroll
+    for (int h = 0; h < H; ++h) d[h] = q[h] * (sv[h] - tq) * invd;
+    if (real) {
+      float4* drow = reinterpret_cast<float4*>(dl + (size_t)e * HP);
+      drow[0] = make_float4(d[0], d[1], d[2], d[3]);
+      drow[1] = make_float4(d[4], d[5], d[6], d[7]);
+      drow[2] = make_float4(d[8], 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; ++h) dsum[h] += d[h];
+    }
+  }
+  // per-node sums over the group (fixed butterfly: deterministic)
+  float dself[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dsum[h] = group_allreduce<G>(dsum[h]);
+    dself[h] = group_allreduce<G>(self ? d[h] : 0.f);
+  }
+  if (!valid || k != 0) return;
+  float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
+  a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
+  a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
+  a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
+  float4* bq = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
+  bq[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
+  bq[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
+  bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
 }
 
 

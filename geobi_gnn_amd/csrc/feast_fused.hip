@@ -72,65 +72,6 @@ template <int C, int MODE, int LC>
 constexpr int fused_lds_floats() { return Shape<C, MODE>::TILE_FLOATS + Shape<C, MODE>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0); }
 constexpr int fused_k(int C, int MODE) { return MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP; }
 
-// One lane's share of a row: PV floats per piece
-
-// acc += sum_v  (lane OWNER's dz[v]) * x[v]  for the PV floats of one piece: the row broadcast rides on the FMA's first
-// operand (v_fmac_f32_dpp row_newbcast, gfx90a+), no separate move.  Every lane of the 16-lane row must be active: a
-// source lane EXEC has switched off does not deliver.  The leading s_nop covers the two wait states a DPP read needs
-// after a VALU write of the same register -- the compiler's hazard pass does not look inside the statement.
-template <int OWNER, int PV>
-__device__ __forceinline__ void fmac_bcast(float& acc, const float* dz, const float* x) {
-  static_assert(OWNER >= 0 && OWNER < 16 && (PV == 4 || PV == 2), "a DPP row has 16 lanes");
-#define GEOBI_FB(M)                                                                                                   \
-  if constexpr (OWNER == M) {                                                                                         \
-    if constexpr (PV == 4)                                                                                            \
-      asm("s_nop 1\n\t"                                                                                               \
-          "v_fmac_f32_dpp %0, %1, %5 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
-          "v_fmac_f32_dpp %0, %2, %6 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
-          "v_fmac_f32_dpp %0, %3, %7 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
-          "v_fmac_f32_dpp %0, %4, %8 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
-          : "+v"(acc)                                                                                                 \
-          : "v"(dz[0]), "v"(dz[1]), "v"(dz[2]), "v"(dz[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));              \
-    else                                                                                                              \
-      asm("s_nop 1\n\t"                                                                                               \
-          "v_fmac_f32_dpp %0, %1, %3 row_newbcast:" #M " row_mask:0xf bank_mask:0xf\n\t"                              \
-          "v_fmac_f32_dpp %0, %2, %4 row_newbcast:" #M " row_mask:0xf bank_mask:0xf"                                  \
-          : "+v"(acc)                                                                                                 \
-          : "v"(dz[0]), "v"(dz[1]), "v"(x[0]), "v"(x[1]));                                                            \
-  }
-  GEOBI_FB(0) GEOBI_FB(1) GEOBI_FB(2) GEOBI_FB(3) GEOBI_FB(4) GEOBI_FB(5) GEOBI_FB(6) GEOBI_FB(7)
-  GEOBI_FB(8) GEOBI_FB(9) GEOBI_FB(10) GEOBI_FB(11) GEOBI_FB(12) GEOBI_FB(13) GEOBI_FB(14) GEOBI_FB(15)
-#undef GEOBI_FB
-}
-
-// f(integral_constant<int, I>) for I in [0, N): loop indices that must be constants (DPP controls, register slots)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-template <int PV>
-__device__ __forceinline__ void load_piece(const float* __restrict__ ptr, float* v) {
-  if constexpr (PV == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(ptr);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if constexpr (PV == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(ptr);
-    v[0] = t.x; v[1] = t.y;
-  } else {
-    v[0] = ptr[0];
-  }
-}
-template <int PV>
-__device__ __forceinline__ void store_piece(float* ptr, const float* v) {
-  if constexpr (PV == 4) *reinterpret_cast<float4*>(ptr) = make_float4(v[0], v[1], v[2], v[3]);
-  else if constexpr (PV == 2) *reinterpret_cast<float2*>(ptr) = make_float2(v[0], v[1]);
-  else ptr[0] = v[0];
-}
-
 #ifdef GEOBI_FUSED_STAMPS
 // Diagnostic build only (tools/build_variant.sh ... -DGEOBI_FUSED_STAMPS): shader-clock stamps of wave 0 of each
 // workgroup at the phase boundaries, written to a buffer nothing else reads.
@@ -523,138 +464,9 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
   __syncthreads();
   GEOBI_STAMP_BWD(3);
 
-  // ---- row pass, lane = edge: the 16 lanes of a node's group each take one in-edge (plus one pseudo-edge for the self
-  // loop) and form all nine dot products s_h = dz_i[h,:] . x_j on their own -- the neighbour row is the lane's private
-  // read (C/4 16-B loads in flight at once), the node's dz row comes from the LDS tile as broadcast reads -- so the
-  // softmax backward needs no cross-lane step at all, dl rows leave as 48 contiguous bytes per lane, and only the
-  // per-node sums are reduced over the group once per 16 edges.
-  const int g = lane / G, k = lane % G;
-  const int nl = wave * NPW + g;
-  const int node = tile * TN + nl;
-  const bool valid = node < N;
-  const int ns = valid ? node : N - 1;
-  const int rs = rowptr[ns];
-  const int deg = valid ? rowptr[ns + 1] - rs : -1;          // items = deg real edges + the self loop; none if invalid
-  // The node's dz row [9][C], one piece per lane and slot (piece p -> slot p / 16, lane p % 16): read from the tile
-  // once; the dot products fetch each piece from its owner lane with a row broadcast (DPP), not from LDS again --
-  // 16 lanes re-reading the same 144 pieces per edge chunk made the row pass LDS-bandwidth bound.
-  constexpr int VW = (C % 4 == 0) ? 4 : 2;                   // floats per piece
-  constexpr int NQ = C / VW;                                 // pieces per head
-  constexpr int NPIECE = H * NQ, NSLOT = (NPIECE + G - 1) / G;
-  float dzr[NSLOT][VW];
-  {
-    const float* zrow = s_z + nl * LDZ;
-#pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl) {
-      const int pidx = sl * G + k;
-      if (pidx < NPIECE) load_piece<VW>(zrow + pidx * VW, dzr[sl]);
-      else {
-#pragma unroll
-        for (int v = 0; v < VW; ++v) dzr[sl][v] = 0.f;
-      }
-    }
-  }
-  const int Cb = C - Ca;
-  constexpr int XB = NQ % 4 == 0 ? 4 : NQ;                   // row pieces per batch (16 channels, or the whole short row)
-  static_assert(NQ % XB == 0 && XB <= 4, "whole batches");
-
-  float cc[H], qs[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
-  softmax9(qs);
-  float xc[LC > 0 ? LC : 1];
-  if constexpr (LC > 0) load_row<LC>(xa + (size_t)ns * LC, xc);
-  const float invd = 1.0f / (float)(deg + 1);
-  float dsum[H], dself[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) { dsum[h] = 0.f; dself[h] = 0.f; }
-
-  for (int base = 0; base <= deg; base += G) {
-    const int idx = base + k;
-    const bool real = idx < deg, self = idx == deg;
-    {  // every lane of the group runs the dot products (a row broadcast reads 0 from a lane EXEC has switched off);
-       // lanes past the node's items work on the node's own row and drop the result
-      const int e = rs + idx;
-      const int j = real ? col[e] : ns;
-      float q[H];
-      if (real) {
-        if constexpr (LC > 0) {
-          float d[LC];
-          load_row<LC>(xa + (size_t)j * LC, d);
-#pragma unroll
-          for (int i = 0; i < LC; ++i) d[i] -= xc[i];
-          edge_logits<LC>(d, s_u, cc, q);
-        } else {
-          float pc[H], pn[H];
-          load_hp(p + (size_t)ns * HP, pc);
-          load_hp(p + (size_t)j * HP, pn);
-#pragma unroll
-          for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
-        }
-        softmax9(q);
-      } else {
-#pragma unroll
-        for (int h = 0; h < H; ++h) q[h] = qs[h];
-      }
-      // nine dot products over the row, channels in ascending order; the row arrives in batches of XB pieces, every
-      // piece of a batch requested before any is used
-      float sv[H];
-#pragma unroll
-      for (int h = 0; h < H; ++h) sv[h] = 0.f;
-      const float* ra = xa + (size_t)j * Ca;
-      const float* rb = xb + (size_t)j * Cb - Ca;                          // indexed by the channel of the whole row
-      static_for<0, NQ / XB>([&](auto bi) {
-        constexpr int q0 = decltype(bi)::value * XB;
-        const float* src = q0 * VW < Ca ? ra : rb;                          // a batch never straddles the two inputs
-        float xj[XB][VW];
-#pragma unroll
-        for (int qd = 0; qd < XB; ++qd) load_piece<VW>(src + (q0 + qd) * VW, xj[qd]);
-        static_for<0, XB>([&](auto qi) {
-          constexpr int qd = decltype(qi)::value;
-          static_for<0, H>([&](auto hi) {
-            constexpr int h = decltype(hi)::value;
-            constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
-            fmac_bcast<owner, VW>(sv[h], dzr[sl], xj[qd]);
-          });
-        });
-      });
-      float tq = 0.f;
-#pragma unroll
-      for (int h = 0; h < H; ++h) tq = fmaf(q[h], sv[h], tq);
-      float d[HP];
-#pragma unroll
-      for (int h = 0; h < H; ++h) d[h] = q[h] * (sv[h] - tq) * invd;
-      d[9] = d[10] = d[11] = 0.f;
-      if (real) {
-        float4* drow = reinterpret_cast<float4*>(dl + (size_t)e * HP);
-        drow[0] = make_float4(d[0], d[1], d[2], d[3]);
-        drow[1] = make_float4(d[4], d[5], d[6], d[7]);
-        drow[2] = make_float4(d[8], 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int h = 0; h < H; ++h) dsum[h] += d[h];
-      } else if (self) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) dself[h] = d[h];
-      }
-    }
-  }
-  GEOBI_STAMP_BWD(4);
-  // per-node sums over the group (fixed butterfly: deterministic)
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    dsum[h] = group_allreduce<G>(dsum[h]);
-    dself[h] = group_allreduce<G>(dself[h]);
-  }
-  GEOBI_STAMP_BWD(5);
-  if (!valid || k != 0) return;
-  float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
-  a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
-  a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
-  a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
-  float4* bq = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
-  bq[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
-  bq[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
-  bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
+  // ---- row pass over the tile's nodes, lane = edge (feast_dev.h): the dz rows come from the LDS tile
+  rowpass_edge_node<C, LC>(s_z + (wave * NPW + lane / G) * LDZ, xa, xb, Ca, p, cvec, s_u, rowptr, col, N,
+                              tile * TN + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
 }
 
 // Packed weights of the forward:  Bp[kb][half][col][s] = lin.weight[h * Cout + col, kin] for k = 8 kb + 4 half + s
