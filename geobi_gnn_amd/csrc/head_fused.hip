@@ -123,34 +123,52 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
 }
 
 // ----------------------------------------------------------------------------- backward
-// Persistent blocks of 4 waves; all waves of a block work on the same 32-node tile, wave w owning the
-// hidden chunks {w, w+4, ..., w+28}.  Per chunk: recompute h (16 MFMA), dh in registers, then
+// Persistent blocks of 8 waves, one block per CU = two waves per SIMD: a dependent MFMA chain blocks its wave's
+// instruction stream for the chain's whole duration (in-order issue), so only ANOTHER wave on the SIMD can run the
+// VALU / LDS stretches under it.  All waves of a block work on the same 32-node tile, wave w owning the hidden
+// chunks {w, w+8, w+16, w+24}.  Per chunk: recompute h (16 MFMA), dh in registers, then
 //   dW1^T[k, j] += x^T dh      -- dh (a C/D tile) is the B operand as it stands ("accumulator" pairing)
-//   dx[n, k]    += dh W1       -- dh transposed through a 4.5 KB per-wave LDS tile
+//   dx[n, k]    += dh W1       -- dh transposed through a 2 KB per-wave LDS tile, 16 node rows at a time
 // dW1 / dW2 / db1 partial sums stay in registers across tiles and are written once per block; a
 // second kernel adds the per-block slabs in a fixed order (deterministic, no atomics).
+#ifdef GEOBI_HEAD_STAMPS
+// Diagnostic build only: shader-clock time wave 0 of every block spends between the phase boundaries of a chunk,
+// summed over the block's chunks (tools/head_stamps.py).
+__device__ unsigned long long g_head_stamps[1024][8];
+#define GEOBI_HS(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); hs_acc[i] += now_ - hs_t; hs_t = now_; } while (0)
+#else
+#define GEOBI_HS(i) do { } while (0)
+#endif
+
+constexpr int HBW = 8;                 // waves per block of the backward kernel
+constexpr int HCPW = NCHUNK / HBW;     // hidden chunks per wave and tile
+
 template <int NOUT>
-__global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
+__global__ __launch_bounds__(512, 1) void head_bwd_fused_kernel(
     const float* __restrict__ x, int N, int ntiles, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, float slope, const float* __restrict__ graw, float* __restrict__ dx,
     float* __restrict__ p_dw1, float* __restrict__ p_dw2, float* __restrict__ p_db1, float* __restrict__ p_db2) {
   // The block's running sums live in LDS (all 160 KiB of it: 128 KiB dW1^T tiles, 12 KiB dW2, 4 KiB
-  // db1, 16 KiB transposition / fold scratch); every LDS word has exactly one writer lane, so the
+  // db1, 16 KiB transposition / fold scratch: 2 KiB per wave); every LDS word has exactly one writer lane, so the
   // accumulation order is fixed.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sW1 = lds;                                  // [NCHUNK][16][64]
   float* sW2 = sW1 + NCHUNK * 16 * 64;               // [3][HID]
   float* sB1 = sW2 + 3 * HID;                        // [HID]
-  float* sT = sB1 + HID;                             // [4][32][32] dh transposition, reused as [4][16][64]
+  float* sT = sB1 + HID;                             // [8][16][32] dh transposition, reused as [8][8][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  for (int i = threadIdx.x; i < NCHUNK * 16 * 64 + 3 * HID + HID; i += 256) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < NCHUNK * 16 * 64 + 3 * HID + HID; i += 64 * HBW) lds[i] = 0.f;
   __syncthreads();
 
   float db2a[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) db2a[o] = 0.f;
-  float* tw = sT + wave * 1024;
+  float* tw = sT + wave * 512;
+#ifdef GEOBI_HEAD_STAMPS
+  unsigned long long hs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long hs_t = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int n0 = t * 32;
@@ -170,21 +188,31 @@ __global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
     f32x16 dxacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dxacc[r] = 0.f;
+    GEOBI_HS(0);                                   // tile prologue (x rows, output gradients)
 
-    for (int cc = 0; cc < 8; ++cc) {
-      const int c = wave + 4 * cc;
+    // Order inside a chunk (s_memtime stamps, tools/head_stamps.py): the W1 columns of the dx product and the next
+    // chunk's W1 rows are requested before h is waited for; the dW1 chain is issued as soon as dh exists, the dx chain
+    // right behind the transposition, the db1 / dW2 sums after them; the dW1 tile is added to its LDS copy last.
+    float bw[16];
+    load16(w1 + (size_t)(wave * 32 + l31) * CIN + 16 * half, bw);
+    for (int cc = 0; cc < HCPW; ++cc) {
+      const int c = wave + HBW * cc;
       const int j = c * 32 + l31;
-      float bw[16];
-      load16(w1 + (size_t)j * CIN + 16 * half, bw);
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], bw[s], acc, 0, 0, 0);
+      GEOBI_HS(1);                                 // recompute chain issued
+      float bq[16];
+      const float* wq = w1 + (size_t)(c * 32 + 16 * half) * CIN + l31;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bq[s] = wq[s * CIN];
       const float b1v = b1[j];
       float w2v[NOUT], dw2c[NOUT];
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) { w2v[o] = w2[(size_t)o * HID + j]; dw2c[o] = 0.f; }
+      load16(w1 + (size_t)((wave + HBW * ((cc + 1) % HCPW)) * 32 + l31) * CIN + 16 * half, bw);   // next chunk's rows
       float dh[16];
       float db1c = 0.f;
 #pragma unroll
@@ -200,6 +228,43 @@ __global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
         dh[r] = hpre > 0.f ? gh : gh * slope;
         db1c += dh[r];
       }
+      GEOBI_HS(2);                                 // waited for h, dh formed
+      // dW1^T chunk tile [k x j]: A = x^T (ax2), B = dh as it stands
+      f32x16 tacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tacc[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax2[r], dh[r], tacc, 0, 0, 0);
+      // dx: transpose dh through LDS (XOR-swizzled 16-B slots) -> A operand [node][j]; B = W1 rows.  The scratch
+      // holds 16 node rows: rows 0..15 (registers r < 8) serve lanes l31 < 16, rows 16..31 the others.
+      float ad[16];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = 8 * pass + r8;
+          const int row = acc_row(r, half) - 16 * pass;
+          tw[row * 32 + (l31 ^ ((row & 7) << 2))] = dh[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((l31 >> 4) == pass) {
+          const int row = l31 & 15;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(&tw[row * 32 + ((16 * half + 4 * q) ^ ((row & 7) << 2))]);
+            ad[4 * q] = v.x; ad[4 * q + 1] = v.y; ad[4 * q + 2] = v.z; ad[4 * q + 3] = v.w;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      GEOBI_HS(3);                                 // dW1 chain issued, dh transposed
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dxacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s], bq[s], dxacc, 0, 0, 0);
+      GEOBI_HS(4);                                 // dx chain issued
       // the two halves of a column hold different node rows: fold them, lane < 32 owns the LDS word
       db1c += __shfl_xor(db1c, 32, 64);
       if (half == 0) sB1[j] += db1c;
@@ -208,60 +273,42 @@ __global__ __launch_bounds__(256, 1) void head_bwd_fused_kernel(
         float d = dw2c[o] + __shfl_xor(dw2c[o], 32, 64);
         if (half == 0) sW2[o * HID + j] += d;
       }
-      // dW1^T chunk tile [k x j]: A = x^T (ax2), B = dh as it stands; added to the block's LDS copy
-      f32x16 tacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tacc[r] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax2[r], dh[r], tacc, 0, 0, 0);
+      // the dW1 tile, added to the block's LDS copy
       float* w1c = sW1 + (size_t)c * 16 * 64 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) w1c[r * 64] += tacc[r];
-      // dx: transpose dh through LDS (XOR-swizzled 16-B slots) -> A operand [node][j]; B = W1 rows
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, half);
-        tw[row * 32 + (l31 ^ ((row & 7) << 2))] = dh[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      float ad[16], bq[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = *reinterpret_cast<const float4*>(&tw[l31 * 32 + ((16 * half + 4 * q) ^ ((l31 & 7) << 2))]);
-        ad[4 * q] = v.x; ad[4 * q + 1] = v.y; ad[4 * q + 2] = v.z; ad[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) bq[s] = w1[(size_t)(c * 32 + 16 * half + s) * CIN + l31];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) dxacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s], bq[s], dxacc, 0, 0, 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      GEOBI_HS(5);                                 // sums, dW1 tile added
     }
-    // fold the four waves' dx tiles (scratch reused as [4][16][64])
-    __syncthreads();
+    // fold the eight waves' dx tiles in a fixed order, eight accumulator registers at a time (scratch as [8][8][64])
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sT[(wave * 16 + r) * 64 + lane] = dxacc[r];
-    __syncthreads();
+    for (int hr = 0; hr < 2; ++hr) {
+      __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave * 4 + q;
-      float v = sT[(0 * 16 + r) * 64 + lane] + sT[(1 * 16 + r) * 64 + lane] + sT[(2 * 16 + r) * 64 + lane] +
-                sT[(3 * 16 + r) * 64 + lane];
-      const int node = n0 + acc_row(r, half);
-      if (node < N) dx[(size_t)node * CIN + l31] = v;
+      for (int r8 = 0; r8 < 8; ++r8) sT[(wave * 8 + r8) * 64 + lane] = dxacc[8 * hr + r8];
+      __syncthreads();
+      {
+        const int r8 = wave;                       // wave w folds register 8 hr + w
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < HBW; ++w) v += sT[(w * 8 + r8) * 64 + lane];
+        const int node = n0 + acc_row(8 * hr + r8, half);
+        if (node < N) dx[(size_t)node * CIN + l31] = v;
+      }
     }
     __syncthreads();
+    GEOBI_HS(6);                                   // dx fold over the block's waves, stores
   }
+#ifdef GEOBI_HEAD_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) g_head_stamps[blockIdx.x][i] = hs_acc[i];
+#endif
 
   // per-block partial sums -> slabs
   __syncthreads();
   float* pw = p_dw1 + (size_t)blockIdx.x * (NCHUNK * 16 * 64);
-  for (int i = threadIdx.x; i < NCHUNK * 16 * 64; i += 256) pw[i] = sW1[i];
-  for (int i = threadIdx.x; i < NOUT * HID; i += 256) p_dw2[(size_t)blockIdx.x * NOUT * HID + i] = sW2[i];
-  for (int i = threadIdx.x; i < HID; i += 256) p_db1[(size_t)blockIdx.x * HID + i] = sB1[i];
+  for (int i = threadIdx.x; i < NCHUNK * 16 * 64; i += 64 * HBW) pw[i] = sW1[i];
+  for (int i = threadIdx.x; i < NOUT * HID; i += 64 * HBW) p_dw2[(size_t)blockIdx.x * NOUT * HID + i] = sW2[i];
+  for (int i = threadIdx.x; i < HID; i += 64 * HBW) p_db1[(size_t)blockIdx.x * HID + i] = sB1[i];
   if (wave == 0) {
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
@@ -313,6 +360,12 @@ int bwd_blocks(int64_t N) {
 
 }  // namespace
 
+#ifdef GEOBI_HEAD_STAMPS
+extern "C" int geobi_debug_head_stamps(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_head_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 bool head_fused_supported(int Cin, int K, int nout) { return Cin == CIN && K == HID && (nout == 1 || nout == 3); }
 
 int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -347,7 +400,7 @@ int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
   float* p_db2 = a.take<float>((size_t)blocks * 4);
   GEOBI_REQUIRE(a.ok() && ws, "head_bwd_fused: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int ntiles = cdiv(N, 32);
-  constexpr size_t kLds = (size_t)(NCHUNK * 16 * 64 + 3 * HID + HID + 4 * 32 * 32) * sizeof(float);   // 160 KiB
+  constexpr size_t kLds = (size_t)(NCHUNK * 16 * 64 + 3 * HID + HID + HBW * 16 * 32) * sizeof(float);   // 160 KiB
   static_assert(kLds == 163840, "the backward head kernel uses the whole LDS of a CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -358,10 +411,10 @@ int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
     attr_set = true;
   }
   if (nout == 3)
-    head_bwd_fused_kernel<3><<<blocks, 256, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
+    head_bwd_fused_kernel<3><<<blocks, 64 * HBW, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
                                                        p_db1, p_db2);
   else
-    head_bwd_fused_kernel<1><<<blocks, 256, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
+    head_bwd_fused_kernel<1><<<blocks, 64 * HBW, kLds, s>>>(x, (int)N, ntiles, w1, b1, w2, slope, graw, dx, p_dw1, p_dw2,
                                                        p_db1, p_db2);
   GEOBI_LAUNCH_OK();
   const int total = HID * CIN + HID + nout * HID + nout;
