@@ -94,6 +94,17 @@ int feast_fused_nt(int nout);
 size_t feast_fused_fwd_pack_floats(int Cin, int Cout);
 size_t feast_fused_dx_pack_floats(int Cin, int Cout);
 int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s);
+// one launch for the packed forms of several layers (feast_fused.hip)
+constexpr int kMaxPackBatch = 8;
+struct FusedPackItem {
+  const float* lin_w;
+  const float* u_w;
+  int Cin, Cout;
+  float* wf;     // [Kp, Cout] plain form (NULL: forward form only)
+  float* bf;     // fragment-ordered forward weights
+  float* bdx;    // fragment-ordered dx weights (with wf)
+};
+int feast_fused_pack_batch(const FusedPackItem* items, int n, hipStream_t s);
 int feast_fused_pack_dx(const float* lin_w, const float* u_w, int Cin, int Cout, float* bp, hipStream_t s);
 int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout, int Kp, float* wf, float* bf,
                          float* bdx, hipStream_t s);
@@ -154,7 +165,7 @@ size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
               const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
               int Cout, float slope, float* out, float* p, float* z, float* wf_out, void* ws, size_t ws_bytes,
-              hipStream_t s);
+              hipStream_t s, const float* bf_packed = nullptr);
 size_t feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
 int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,

@@ -83,22 +83,25 @@ __global__ void compose_index_kernel(const int32_t* __restrict__ first, const in
 
 // FeaStConv forward.  Inference: logits and workspace are scratch.  Training (`save`): logits and the packed weights
 // stay for the backward.
+// `packed`: the layer's weights as pack_branch left them (training: every form, the buffer the backward reads;
+// inference: the forward form).
 int conv_fwd(Bump& b, const Level& g, const float* xa, const float* xb, int Ca, int Cb, const geobi_conv_params_t& p,
-             int Cout, float slope, float** out, ConvSave* save, hipStream_t s) {
+             int Cout, float slope, float** out, ConvSave* save, float* packed, hipStream_t s) {
   const int64_t N = g.N;
   float* o = b.take<float>((size_t)N * Cout);
   float *logits = nullptr, *wf = nullptr;
   if (save) {
     logits = b.take<float>((size_t)N * GEOBI_HP);
-    wf = b.take<float>(feast_wpack_floats(Ca + Cb, Cout));
+    wf = packed;
   }
+  const float* bf = save ? packed + feast_wpack_plain_floats(Ca + Cb, Cout) : packed;
   const size_t m = b.mark();
   if (!save) logits = b.take<float>((size_t)N * GEOBI_HP);
   const size_t wsb = feast_fwd_ws_bytes(N, Ca + Cb, Cout);
   void* ws = b.take<char>(wsb);
   if (!b.ok) return kArenaFull;
   GEOBI_TRY(feast_fwd(xa, Cb ? xb : nullptr, Ca, Cb, N, g.E, g.rowptr, g.col, p.lin_w, p.u_w, p.c, p.bias, Cout, slope, o,
-                      logits, nullptr, wf, ws, wsb, s));
+                      logits, nullptr, wf, ws, wsb, s, bf));
   b.release(m);
   if (save) {
     save->g = &g; save->xa = xa; save->xb = Cb ? xb : nullptr; save->Ca = Ca; save->Cb = Cb; save->Cout = Cout;
@@ -257,22 +260,43 @@ int gnn_forward(Bump& b, const Level& L0, const float* x_in, int Cin, const geob
   Level& L0r = tape ? tape->L[0] : const_cast<Level&>(L0);
   if (tape) { tape->L[0] = L0; tape->Cin = Cin; }
   auto cs = [&](int i) { return tape ? &tape->conv[i] : nullptr; };
-  GEOBI_TRY(conv_fwd(b, L0r, x_in, nullptr, Cin, 0, p.conv[0], 32, kLeak, &x0, cs(0), s));
+  // the packed weights of the branch's eight layers, one launch (training: every form, kept for the backward;
+  // inference: the forward forms)
+  const int plan[8][2] = {{Cin, 32}, {32, 64}, {64, 128}, {128, 128}, {128, 64}, {128, 64}, {64, 32}, {64, 32}};
+  float* pk[8];
+  {
+    FusedPackItem items[8];
+    for (int i = 0; i < 8; ++i) {
+      const int ci = plan[i][0], co = plan[i][1];
+      pk[i] = b.take<float>(tape ? feast_wpack_floats(ci, co) : feast_fused_fwd_pack_floats(ci, co));
+      if (!b.ok) return kArenaFull;
+      items[i].lin_w = p.conv[i].lin_w; items[i].u_w = p.conv[i].u_w; items[i].Cin = ci; items[i].Cout = co;
+      if (tape) {
+        items[i].wf = pk[i];
+        items[i].bf = pk[i] + feast_wpack_plain_floats(ci, co);
+        items[i].bdx = items[i].bf + feast_fused_fwd_pack_floats(ci, co);
+      } else {
+        items[i].wf = nullptr; items[i].bf = pk[i]; items[i].bdx = nullptr;
+      }
+    }
+    GEOBI_TRY(feast_fused_pack_batch(items, 8, s));
+  }
+  GEOBI_TRY(conv_fwd(b, L0r, x_in, nullptr, Cin, 0, p.conv[0], 32, kLeak, &x0, cs(0), pk[0], s));
   GEOBI_TRY(pool_layer(b, L0r, x0, 32, pool_mean, p1, tape ? &tape->pool[0] : nullptr, s));
   Level& L1 = tape ? tape->L[1] : L1s;
   L1 = p1.coarse;
-  GEOBI_TRY(conv_fwd(b, L1, p1.x, nullptr, 32, 0, p.conv[1], 64, kLeak, &x1, cs(1), s));
+  GEOBI_TRY(conv_fwd(b, L1, p1.x, nullptr, 32, 0, p.conv[1], 64, kLeak, &x1, cs(1), pk[1], s));
   GEOBI_TRY(pool_layer(b, L1, x1, 64, pool_mean, p2, tape ? &tape->pool[1] : nullptr, s));
   Level& L2 = tape ? tape->L[2] : L2s;
   L2 = p2.coarse;
-  GEOBI_TRY(conv_fwd(b, L2, p2.x, nullptr, 64, 0, p.conv[2], 128, kLeak, &x2a, cs(2), s));
-  GEOBI_TRY(conv_fwd(b, L2, x2a, nullptr, 128, 0, p.conv[3], 128, kLeak, &x2, cs(3), s));
+  GEOBI_TRY(conv_fwd(b, L2, p2.x, nullptr, 64, 0, p.conv[2], 128, kLeak, &x2a, cs(2), pk[2], s));
+  GEOBI_TRY(conv_fwd(b, L2, x2a, nullptr, 128, 0, p.conv[3], 128, kLeak, &x2, cs(3), pk[3], s));
   GEOBI_TRY(unpool_rows(b, x2, p2.unpool, 128, L1.N, &up2, s));
-  GEOBI_TRY(conv_fwd(b, L1, up2, nullptr, 128, 0, p.conv[4], 64, 1.0f, &r1, cs(4), s));
-  GEOBI_TRY(conv_fwd(b, L1, x1, r1, 64, 64, p.conv[5], 64, kLeak, &x1b, cs(5), s));
+  GEOBI_TRY(conv_fwd(b, L1, up2, nullptr, 128, 0, p.conv[4], 64, 1.0f, &r1, cs(4), pk[4], s));
+  GEOBI_TRY(conv_fwd(b, L1, x1, r1, 64, 64, p.conv[5], 64, kLeak, &x1b, cs(5), pk[5], s));
   GEOBI_TRY(unpool_rows(b, x1b, p1.unpool, 64, L0.N, &up1, s));
-  GEOBI_TRY(conv_fwd(b, L0r, up1, nullptr, 64, 0, p.conv[6], 32, 1.0f, &r3, cs(6), s));
-  GEOBI_TRY(conv_fwd(b, L0r, x0, r3, 32, 32, p.conv[7], 32, kLeak, &out, cs(7), s));
+  GEOBI_TRY(conv_fwd(b, L0r, up1, nullptr, 64, 0, p.conv[6], 32, 1.0f, &r3, cs(6), pk[6], s));
+  GEOBI_TRY(conv_fwd(b, L0r, x0, r3, 32, 32, p.conv[7], 32, kLeak, &out, cs(7), pk[7], s));
   *feat = out;
   bo.nodes[0] = L0.N; bo.nodes[1] = L1.N; bo.nodes[2] = L2.N;
   const PoolResult* pr[2] = {&p1, &p2};
@@ -429,7 +453,8 @@ extern "C" size_t geobi_net_forward_arena_bytes(int64_t V, int64_t Ev, int64_t F
   // integer arrays of two pooling layers (bounded by the level-0 sizes) and their workspaces
   auto branch = [](int64_t N, int64_t E) {
     return (size_t)N * (4 * 512 + 4 * 2 * 16) + (size_t)E * (4 * 2 * 8) + match_coarsen_ws_bytes(N) +
-           pool_edge_rows_ws_bytes(N) + feast_fwd_ws_bytes(N, 128, 128) + ((size_t)8 << 20);
+           pool_edge_rows_ws_bytes(N) + feast_fwd_ws_bytes(N, 128, 128) + ((size_t)8 << 20) +
+           ((size_t)4 << 20);                     // the branch's packed forward weights (< 2 MB)
   };
   return branch(V, Ev) + branch(F, Ef) + (size_t)F * 12 * 4 + ((size_t)16 << 20);
 }

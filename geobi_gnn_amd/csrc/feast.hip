@@ -659,7 +659,9 @@ size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout) {
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t Ecap, const int32_t* rowptr_in,
               const int32_t* col_in, const float* lin_w, const float* u_w, const float* cvec, const float* bias,
               int Cout, float slope, float* out, float* p, float* z, float* wf_out, void* ws, size_t ws_bytes,
-              hipStream_t s) {
+              hipStream_t s, const float* bf_packed) {
+  // bf_packed (fused path): the layer's fragment-ordered forward weights, packed by the caller (feast_fused_pack_batch,
+  // one launch for a branch's eight layers); with wf_out also given, wf_out holds every form already.
   const int Cin = Ca + Cb;
   GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_fwd: bad node count");
   GEOBI_REQUIRE(Cb == 0 || Ca == Cb, "feast_fwd: a split input must have two equal halves");
@@ -668,12 +670,19 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   if (z == nullptr) {
     // Fused path: aggregation + node transform in one kernel, z never reaches HBM (feast_fused.hip).
     const size_t plain = feast_wpack_plain_floats(Cin, Cout);
-    float* bf = wf_out ? wf_out + plain : a.take<float>(feast_fused_fwd_pack_floats(Cin, Cout));
-    GEOBI_REQUIRE(a.ok() && bf, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
-    if (wf_out != nullptr) {      // + the backward's packed forms (Wf for dz, the fused dx weights), one launch
-      GEOBI_TRY(feast_fused_pack_all(lin_w, u_w, Cin, Cout, Kp, wf_out, bf, bf + feast_fused_fwd_pack_floats(Cin, Cout), s));
+    const float* bf = bf_packed;
+    if (bf == nullptr) {
+      float* bfw = wf_out ? wf_out + plain : a.take<float>(feast_fused_fwd_pack_floats(Cin, Cout));
+      GEOBI_REQUIRE(a.ok() && bfw, "feast_fwd: workspace too small (%zu < %zu)", ws_bytes, a.off);
+      bf = bfw;
+    }
+    if (bf_packed != nullptr) {
+      // packed by the caller
+    } else if (wf_out != nullptr) {      // + the backward's packed forms (Wf for dz, the fused dx weights), one launch
+      float* bfw = wf_out + plain;
+      GEOBI_TRY(feast_fused_pack_all(lin_w, u_w, Cin, Cout, Kp, wf_out, bfw, bfw + feast_fused_fwd_pack_floats(Cin, Cout), s));
     } else {
-      GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, bf, s));
+      GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, const_cast<float*>(bf), s));
     }
     const int LCf = edge_logit_channels(Cin, Cb);
     if (LCf == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));

@@ -536,6 +536,54 @@ __global__ void pack_fused_all_kernel(const float* __restrict__ lin_w, const flo
   }
 }
 
+// Every packed form of SEVERAL layers in one launch (a branch's eight FeaSt layers: 8 launches of ~4 us -> 1).
+// all != 0: wf | bf | bdx per layer (training);  all == 0: bf only (inference).
+struct PackBatch {
+  FusedPackItem it[kMaxPackBatch];
+  int64_t start[kMaxPackBatch + 1];      // element offsets of the layers in the launch's index space
+  int n, all;
+};
+
+__global__ void pack_fused_batch_kernel(PackBatch pb) {
+  int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= pb.start[pb.n]) return;
+  int l = 0;
+  while (gidx >= pb.start[l + 1]) ++l;
+  const FusedPackItem& d = pb.it[l];
+  int idx = (int)(gidx - pb.start[l]);
+  const int Cin = d.Cin, Cout = d.Cout;
+  const int Kp = (H * Cin + 3) / 4 * 4;          // feast_ldz
+  const int KDf = fused_k(Cin, 0), NPf = 32 * (Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4));
+  const int KDx = fused_k(Cout, 1), NPx = 32 * (Cin <= 32 ? 1 : (Cin <= 64 ? 2 : 4));
+  const int n_wf = pb.all ? Kp * Cout : 0, n_bf = KDf * NPf, n_bx = pb.all ? KDx * NPx : 0;
+  if (idx < n_wf) {
+    const int kk = idx / Cout, o = idx % Cout;
+    const int h = kk / Cin, k = kk % Cin;
+    d.wf[idx] = (h < H) ? d.lin_w[((size_t)h * Cout + o) * Cin + k] : 0.f;
+    return;
+  }
+  idx -= n_wf;
+  if (idx < n_bf) {
+    const int sidx = idx & 3, colx = (idx >> 2) % NPf, rest = (idx >> 2) / NPf;
+    const int k = 8 * (rest >> 1) + 4 * (rest & 1) + sidx;
+    float v = 0.f;
+    if (k < H * Cin && colx < Cout) v = d.lin_w[((size_t)(k / Cin) * Cout + colx) * Cin + (k % Cin)];
+    d.bf[idx] = v;
+    return;
+  }
+  idx -= n_bf;
+  if (idx < n_bx) {
+    const int sidx = idx & 3, colx = (idx >> 2) % NPx, rest = (idx >> 2) / NPx;
+    const int k = 8 * (rest >> 1) + 4 * (rest & 1) + sidx;
+    float v = 0.f;
+    if (colx < Cin) {
+      if (k < H * Cout) v = d.lin_w[(size_t)k * Cin + colx];
+      else if (k < H * Cout + H) v = d.u_w[(size_t)(k - H * Cout) * Cin + colx];
+    }
+    d.bdx[idx] = v;
+  }
+}
+
 template <int C, int MODE, int LC, int NT>
 int launch_one(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
@@ -656,6 +704,27 @@ int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout
   const int KDf = fused_k(Cin, 0), NPf = 32 * feast_fused_nt(Cout), KDx = fused_k(Cout, 1), NPx = 32 * feast_fused_nt(Cin);
   const int64_t total = (int64_t)Kp * Cout + (int64_t)KDf * NPf + (int64_t)KDx * NPx;
   pack_fused_all_kernel<<<cdiv(total, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, Kp, KDf, NPf, KDx, NPx, wf, bf, bdx);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+// items[i].wf != NULL for every i (all forms: wf, then bf and bdx behind it as feast_wpack_floats lays them out) or for
+// none (items[i].bf only)
+int feast_fused_pack_batch(const FusedPackItem* items, int n, hipStream_t s) {
+  GEOBI_REQUIRE(n > 0 && n <= kMaxPackBatch, "pack batch: %d layers (max %d)", n, kMaxPackBatch);
+  PackBatch pb;
+  pb.n = n;
+  pb.all = items[0].wf != nullptr;
+  pb.start[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    pb.it[i] = items[i];
+    const int Cin = items[i].Cin, Cout = items[i].Cout;
+    GEOBI_REQUIRE((items[i].wf != nullptr) == (pb.all != 0), "pack batch: mixed modes");
+    int64_t cnt = (int64_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout);
+    if (pb.all) cnt += (int64_t)feast_ldz(Cin) * Cout + (int64_t)fused_k(Cout, 1) * 32 * feast_fused_nt(Cin);
+    pb.start[i + 1] = pb.start[i] + cnt;
+  }
+  pack_fused_batch_kernel<<<cdiv(pb.start[n], 256), 256, 0, s>>>(pb);
   GEOBI_LAUNCH_OK();
   return 0;
 }
