@@ -367,8 +367,20 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
 // and dcs (dpn + the self edge's share).  The mirror image of the forward kernel: matrix phase first, gather second;
 // the node's dz row is read into registers and its LDS row then serves as the parking slots of its edges.
 // Shapes: C = Cin <= 64 (one chunk); Cout in {32, 64, 128} (the reduction length of the matrix phase).
+// Rows (target nodes) per tile of the fused backward row pass: 32 = one full MFMA tile, 8 waves, two workgroups per CU
+// (78 KB of LDS each); 16 = half-used MFMA tiles, 4 waves, FOUR workgroups per CU (39 KB each) whose phases interleave
+// better -- but the matrix phase then does twice the MFMA work per node, and that costs more than the interleaving
+// gains: 262 against 265 M-edges/s in a same-box A/B (tools/ab_lib.sh).  32 is the product build.
+#ifndef GEOBI_K2_ROWS
+#define GEOBI_K2_ROWS 32
+#endif
+constexpr int RT = GEOBI_K2_ROWS;
+constexpr int KW = RT / NPW;           // waves per workgroup
+constexpr int KT = 64 * KW;            // threads per workgroup
+static_assert(RT == 32 || RT == 16, "a tile is one MFMA tile or half of one");
+
 template <int C, int LC, int COUT>
-__global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
+__global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
     const float* __restrict__ ul, const float* __restrict__ gout, const float* __restrict__ out_act, float slope,
@@ -380,22 +392,22 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
   constexpr int GL = COUT + 4;                   // g tile row stride: conflict-free ds_read_b128 of the A operand
   static_assert(C <= 64, "one chunk");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_g = smem;                             // [32][GL]
-  float* s_z = smem + TN * GL;                   // [32][LDZ]
-  float* s_u = s_z + TN * LDZ;
+  float* s_g = smem;                             // [RT][GL]
+  float* s_z = smem + RT * GL;                   // [RT][LDZ]
+  float* s_u = s_z + RT * LDZ;
   if constexpr (LC > 0) stage_u<LC>(ul, s_u);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = xcd_block(blockIdx.x, gridDim.x);
-  if (tile * TN >= N) return;
+  if (tile * RT >= N) return;
   GEOBI_STAMP_BWD(0);
 
   // ---- g tile: gradient through the fused leaky-relu, kept for the MFMAs and written out for the dx kernel
   {
     constexpr int Q = COUT / 4;
-    for (int i = threadIdx.x; i < TN * Q; i += 512) {
+    for (int i = threadIdx.x; i < RT * Q; i += KT) {
       const int r = i / Q, c4 = (i - r * Q) * 4;
-      const int gn = tile * TN + r;
+      const int gn = tile * RT + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gn < N) {
         v = *reinterpret_cast<const float4*>(gout + (size_t)gn * COUT + c4);
@@ -412,51 +424,57 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
   __syncthreads();
   GEOBI_STAMP_BWD(1);
 
-  // ---- matrix phase: dz[32, K] = g[32, COUT] Wf^T; wave w owns column tiles w, w + 8, w + 16
-  // The weights of all of a wave's tiles are requested together, four k-blocks at a time: one exposed load latency
-  // per batch instead of one per tile.
+  // ---- matrix phase: dz[RT, K] = g[RT, COUT] Wf^T; wave w owns column tiles w, w + KW, w + 2 KW, ...
+  // The weights of up to three of a wave's tiles are requested together, four k-blocks at a time: one exposed load
+  // latency per batch instead of one per tile.  RT = 16: the A operand's rows 16..31 repeat rows 0..15 and the
+  // accumulator rows >= 16 (registers 8..15) are dropped.
   {
     const int hf = lane >> 5, l31 = lane & 31;
     constexpr int NKB = COUT / 8;
-    constexpr int MAXT = (NCT + NW - 1) / NW;                      // column tiles per wave (<= 3)
+    constexpr int MAXT = (NCT + KW - 1) / KW;                      // column tiles per wave
+    constexpr int TB = MAXT < 3 ? MAXT : 3;                        // tiles per round (48 accumulator registers)
     constexpr int HB = 4;                                          // k-blocks per batch of weight loads
     static_assert(NKB % HB == 0, "whole batches");
-    const float* arow = s_g + l31 * GL + 4 * hf;
-    const float* brow[MAXT];
-    f32x16 acc[MAXT];
+    const float* arow = s_g + (l31 % RT) * GL + 4 * hf;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int ct = wave + t * NW;
-      const int krow = min(ct * 32 + l31, Kp - 1);                 // rows past K: clamped, their columns are never read
-      brow[t] = Wf + (size_t)krow * COUT + 4 * hf;
+    for (int t0 = 0; t0 < MAXT; t0 += TB) {
+      const float* brow[TB];
+      f32x16 acc[TB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    }
+      for (int t = 0; t < TB; ++t) {
+        const int ct = wave + (t0 + t) * KW;
+        const int krow = min(ct * 32 + l31, Kp - 1);               // rows past K: clamped, their columns are never read
+        brow[t] = Wf + (size_t)krow * COUT + 4 * hf;
 #pragma unroll
-    for (int b0 = 0; b0 < NKB; b0 += HB) {
-      float4 w[MAXT][HB];
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      }
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t)
+      for (int b0 = 0; b0 < NKB; b0 += HB) {
+        float4 w[TB][HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) w[t][u] = *reinterpret_cast<const float4*>(brow[t] + 8 * (b0 + u));
+        for (int t = 0; t < TB; ++t)
 #pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+          for (int u = 0; u < HB; ++u) w[t][u] = *reinterpret_cast<const float4*>(brow[t] + 8 * (b0 + u));
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t][u].x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t][u].y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t][u].z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t][u].w, acc[t], 0, 0, 0);
+        for (int u = 0; u < HB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+#pragma unroll
+          for (int t = 0; t < TB; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t][u].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t][u].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t][u].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t][u].w, acc[t], 0, 0, 0);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int ct = wave + t * NW;
-      if (ct < NCT) {
+      for (int t = 0; t < TB; ++t) {
+        const int ct = wave + (t0 + t) * KW;
+        if (ct < NCT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[t][r];
+          for (int r = 0; r < (RT == 32 ? 16 : 8); ++r)
+            s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[t][r];
+        }
       }
     }
   }
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused_kernel(
 
   // ---- row pass over the tile's nodes, lane = edge (feast_dev.h): the dz rows come from the LDS tile
   rowpass_edge_node<C, LC>(s_z + (wave * NPW + lane / G) * LDZ, xa, xb, Ca, p, cvec, s_u, rowptr, col, N,
-                              tile * TN + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
+                              tile * RT + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
 }
 
 // Packed weights of the forward:  Bp[kb][half][col][s] = lin.weight[h * Cout + col, kin] for k = 8 kb + 4 half + s
@@ -642,7 +660,7 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
                          hipStream_t s) {
   constexpr int NCT = (H * C + 31) / 32;
   constexpr int LDZ = NCT * 32 + 4;
-  constexpr size_t lds = ((size_t)TN * (COUT + 4) + (size_t)TN * LDZ + (LC > 0 ? LC * HP : 0)) * sizeof(float);
+  constexpr size_t lds = ((size_t)RT * (COUT + 4) + (size_t)RT * LDZ + (LC > 0 ? LC * HP : 0)) * sizeof(float);
   static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -650,7 +668,7 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_rowpass_fused_kernel<C, LC, COUT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+  feast_rowpass_fused_kernel<C, LC, COUT><<<xcd_grid(cdiv(N, RT)), KT, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp, g_out, dl, dpn, dcs, ld_dcs);
   GEOBI_LAUNCH_OK();
   return 0;
