@@ -61,6 +61,59 @@ __global__ __launch_bounds__(256) void feast_logits_kernel(const float* __restri
   dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
 }
 
+// Same product with 16 lanes per node (C >= 32): one thread per node walks its row piece by piece, every load waited
+// for in turn -- 13 us per launch whatever N (6 + 6 launches per step, 10 % of a single-mesh inference).  Here a
+// node's row is ONE coalesced read of its 16-lane group (C / 16 channels per lane), the nine partial dot products are
+// reduced over the group with DPP steps, four nodes per wave.
+template <int C>
+__global__ __launch_bounds__(256) void feast_logits_group_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                                 int Ca, const float* __restrict__ u, int N,
+                                                                 float* __restrict__ p) {
+  constexpr int VEC = C / 16;
+  static_assert(VEC == 2 || VEC == 4 || VEC == 8, "32, 64 or 128 channels");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, k = lane & 15;
+  const int node = (blockIdx.x * 4 + wave) * 4 + g;
+  const int ns = node < N ? node : N - 1;          // every lane takes part in the reductions
+  const int c0 = k * VEC;
+  const float* src = c0 < Ca ? xa + (size_t)ns * Ca + c0 : xb + (size_t)ns * (C - Ca) + (c0 - Ca);
+  float xv[VEC];
+  if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(src);
+    xv[0] = t.x; xv[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(src)[q];
+      xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
+    }
+  }
+  float acc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* ur = u + h * C + c0;              // 9 C floats in all: L1 / L2 resident
+    float a = 0.f;
+    if constexpr (VEC == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(ur);
+      a = fmaf(xv[0], t.x, xv[1] * t.y);
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(ur)[q];
+        a = fmaf(xv[4 * q], t.x, a); a = fmaf(xv[4 * q + 1], t.y, a);
+        a = fmaf(xv[4 * q + 2], t.z, a); a = fmaf(xv[4 * q + 3], t.w, a);
+      }
+    }
+    acc[h] = group_allreduce<16>(a);
+  }
+  if (node < N && k == 0) {
+    float4* dst = reinterpret_cast<float4*>(p + (size_t)node * HP);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------- aggregation
 // G = C / VEC lanes own one centre node (VEC consecutive channels each); a wave owns 64 / G
 // consecutive nodes.  Per group and per chunk of G edges:
@@ -626,6 +679,17 @@ int launch_rowpass(int C, const float* xa, const float* xb, int Ca, const float*
 }
 
 int launch_logits(int C, const float* xa, const float* xb, int Ca, const float* u, int N, float* p, hipStream_t s) {
+  if (C >= 32 && Ca % (C / 16) == 0) {            // a lane's channels never straddle the two input parts
+    const int gb = cdiv(N, 16);
+    switch (C) {
+      case 32: feast_logits_group_kernel<32><<<gb, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+      case 64: feast_logits_group_kernel<64><<<gb, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+      case 128: feast_logits_group_kernel<128><<<gb, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
+      default: return set_error("feast: unsupported channel count %d", C);
+    }
+    GEOBI_LAUNCH_OK();
+    return 0;
+  }
   int blocks = cdiv(N, 256);
   switch (C) {
     case 6: feast_logits_kernel<6><<<blocks, 256, 0, s>>>(xa, xb, Ca, u, N, p); break;
