@@ -318,38 +318,45 @@ __global__ __launch_bounds__(512, 1) void head_bwd_fused_kernel(
   }
 }
 
-__global__ void head_bwd_reduce_kernel(const float* __restrict__ p_dw1, const float* __restrict__ p_dw2,
+// Sum of the per-block slabs in a fixed order.  64 outputs per block, four threads per output: thread (o, q) adds
+// slabs q, q + 4, ... (the loads of different slabs are independent: 16 in flight per thread), the four partial sums
+// meet in LDS in the order q = 0..3.  (One thread per output walking all 256 slabs in dw1's order -- reads 256 B apart --
+// took 38 us for 37 MB.)
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float* __restrict__ p_dw1, const float* __restrict__ p_dw2,
                                        const float* __restrict__ p_db1, const float* __restrict__ p_db2,
                                        int blocks, int nout, int accumulate, float* __restrict__ dw1,
                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
   const int n_dw1 = HID * CIN;
+  const int total = n_dw1 + HID + nout * HID + nout;
+  const float* src = nullptr;
+  size_t stride = 0, off = 0;
+  float* dst = nullptr;
   if (idx < n_dw1) {
-    // dw1[j, k]  <-  slab element (chunk c = j / 32, reg r, lane) with k = row(r, half), j % 32 = lane & 31
-    const int j = idx / CIN, k = idx % CIN;
-    const int half = (k >> 2) & 1, r = (k & 3) + 4 * (k >> 3), lane = (j & 31) + 32 * half;
-    const size_t off = ((size_t)(j >> 5) * 16 + r) * 64 + lane;
-    float s = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < blocks; ++b) s += p_dw1[(size_t)b * (NCHUNK * 16 * 64) + off];
-    dw1[idx] = accumulate ? dw1[idx] + s : s;
+    // threads walk the slab in ITS order (coalesced reads of 37 MB; the 128 KB of writes scatter instead):
+    // slab element (chunk c, reg r, lane)  ->  dw1[j, k] with j = 32 c + (lane & 31), k = row(r, lane >> 5)
+    const int c = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63;
+    const int j = c * 32 + (lane & 31), k = acc_row(r, lane >> 5);
+    src = p_dw1; stride = (size_t)NCHUNK * 16 * 64; off = idx; dst = dw1 + (size_t)j * CIN + k;
   } else if (idx < n_dw1 + HID) {
-    const int j = idx - n_dw1;
-    float s = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < blocks; ++b) s += p_db1[(size_t)b * HID + j];
-    db1[j] = accumulate ? db1[j] + s : s;
+    src = p_db1; stride = HID; off = idx - n_dw1; dst = db1 + off;
   } else if (idx < n_dw1 + HID + nout * HID) {
-    const int e = idx - n_dw1 - HID;
-    float s = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < blocks; ++b) s += p_dw2[(size_t)b * nout * HID + e];
-    dw2[e] = accumulate ? dw2[e] + s : s;
-  } else if (idx < n_dw1 + HID + nout * HID + nout) {
-    const int o = idx - n_dw1 - HID - nout * HID;
-    float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += p_db2[(size_t)b * 4 + o];
-    db2[o] = accumulate ? db2[o] + s : s;
+    src = p_dw2; stride = (size_t)nout * HID; off = idx - n_dw1 - HID; dst = dw2 + off;
+  } else if (idx < total) {
+    src = p_db2; stride = 4; off = idx - n_dw1 - HID - nout * HID; dst = db2 + off;
+  }
+  float s = 0.f;
+  if (src != nullptr) {
+#pragma unroll 16
+    for (int b = q; b < blocks; b += 4) s += src[(size_t)b * stride + off];
+  }
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0 && dst != nullptr) {
+    const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    *dst = accumulate ? *dst + t : t;
   }
 }
 
@@ -418,7 +425,7 @@ int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
                                                        p_db1, p_db2);
   GEOBI_LAUNCH_OK();
   const int total = HID * CIN + HID + nout * HID + nout;
-  head_bwd_reduce_kernel<<<cdiv(total, 256), 256, 0, s>>>(p_dw1, p_dw2, p_db1, p_db2, blocks, nout, accumulate, dw1, db1,
+  head_bwd_reduce_kernel<<<cdiv(total, 64), 256, 0, s>>>(p_dw1, p_dw2, p_db1, p_db2, blocks, nout, accumulate, dw1, db1,
                                                           dw2, db2);
   GEOBI_LAUNCH_OK();
   return 0;
