@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ w,
     const int* __restrict__ ncount, int nbound, int* __restrict__ cnt, const int* __restrict__ rowptr_c,
     int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow,
-    int* __restrict__ total) {
+    int* __restrict__ total, int4* __restrict__ rowinfo) {
   const int lane = threadIdx.x & 63;
   const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
@@ -544,12 +544,23 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
   if (A >= nbound) return;
   const int nc = *ncount;
   if (A >= nc) { if (PASS == 0) cnt[A] = 0; return; }
-  const int ms = segptr[A], me = segptr[A + 1];
-  const int m0 = members[ms];
-  const int m1 = (me - ms > 1) ? members[ms + 1] : -1;
-  const int r0 = rowptr[m0], d0 = rowptr[m0 + 1] - r0;
-  const int r1 = m1 >= 0 ? rowptr[m1] : 0, d1 = m1 >= 0 ? rowptr[m1 + 1] - r1 : 0;
-  if (PASS == 0 && lane == 0 && (d0 + d1 > 64 || me - ms > 2)) atomicOr(overflow, 1);
+  // the members' fine rows: PASS 0 walks segptr -> members -> rowptr (three dependent loads) and leaves the result
+  // for PASS 1, whose chain then starts at the row entries
+  int r0, d0, r1, d1;
+  if (PASS == 0) {
+    const int ms = segptr[A], me = segptr[A + 1];
+    const int m0 = members[ms];
+    const int m1 = (me - ms > 1) ? members[ms + 1] : -1;
+    r0 = rowptr[m0]; d0 = rowptr[m0 + 1] - r0;
+    r1 = m1 >= 0 ? rowptr[m1] : 0; d1 = m1 >= 0 ? rowptr[m1 + 1] - r1 : 0;
+    if (lane == 0) {
+      rowinfo[A] = make_int4(r0, d0, r1, d1);
+      if (d0 + d1 > 64 || me - ms > 2) atomicOr(overflow, 1);
+    }
+  } else {
+    const int4 ri = rowinfo[A];
+    r0 = ri.x; d0 = ri.y; r1 = ri.z; d1 = ri.w;
+  }
   int key = 0x7fffffff;
   float val = 0.f;
   if (lane < d0 + d1) {
@@ -557,17 +568,22 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     int k = cnew[col[e]];
     if (k != A) { key = k; val = w ? w[e] : 0.f; }
   }
-  // bitonic sort, ascending by key
+  // bitonic sort, ascending by key; rows of up to 32 entries (the usual case: two mesh rows) skip the 64-wide merge
+  auto stage = [&](int k, int j) {
+    const int pk = __shfl_xor(key, j, 64);
+    const float pv = __shfl_xor(val, j, 64);
+    const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+    const bool take = keep_min ? (pk < key) : (pk > key);
+    if (take) { key = pk; val = pv; }
+  };
 #pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
+  for (int k = 2; k <= 32; k <<= 1) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int pk = __shfl_xor(key, j, 64);
-      const float pv = __shfl_xor(val, j, 64);
-      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-      const bool take = keep_min ? (pk < key) : (pk > key);
-      if (take) { key = pk; val = pv; }
-    }
+    for (int j = k >> 1; j > 0; j >>= 1) stage(k, j);
+  }
+  if (d0 + d1 > 32) {                            // wave-uniform
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) stage(64, j);
   }
   const int prev = __shfl_up(key, 1, 64);
   const bool head = key != 0x7fffffff && (lane == 0 || prev != key);
@@ -1064,7 +1080,8 @@ int gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float*
 }
 
 size_t pool_edge_rows_ws_bytes(int64_t nbound) {
-  return align_up((size_t)(nbound + 1) * sizeof(int)) + align_up(scan_temp_bytes<int>(nbound + 1)) + 512;
+  return align_up((size_t)(nbound + 1) * sizeof(int)) + align_up(scan_temp_bytes<int>(nbound + 1)) +
+         align_up((size_t)nbound * sizeof(int4)) + 512;
 }
 
 // cnew, (segptr, members) = pair lists built with the bound `nbound` (fine node count), ncount = device
@@ -1079,14 +1096,15 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
   int* cnt = a.take<int>(nbound + 1);
   size_t tb = scan_temp_bytes<int>(nbound + 1);
   void* temp = a.take<char>(tb ? tb : 1);
-  GEOBI_REQUIRE(a.ok() && cnt, "pool_edge_rows: workspace too small");
+  int4* rowinfo = a.take<int4>(nbound);
+  GEOBI_REQUIRE(a.ok() && cnt && rowinfo, "pool_edge_rows: workspace too small");
   int blocks = cdiv(nbound, 4);
   pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   nullptr, nullptr, nullptr, nullptr, overflow, nullptr);
+                                                   nullptr, nullptr, nullptr, nullptr, overflow, nullptr, rowinfo);
   GEOBI_LAUNCH_OK();
   GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
   pool_edge_rows_kernel<1><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   rowptr_c, row_c, col_c, w_c, overflow, count);
+                                                   rowptr_c, row_c, col_c, w_c, overflow, count, rowinfo);
   GEOBI_LAUNCH_OK();
   return 0;
 }
