@@ -235,30 +235,50 @@ __global__ void centroid_kernel(const float* __restrict__ pts, const int* __rest
 // cent == nullptr: the centroid of every adjacent face is formed on the fly from the OLD positions (same
 // expression as centroid_kernel, so the same bits) -- one launch per sweep instead of two, which is what the
 // 60-sweep loop is bound by.
-__global__ void vertex_update_kernel(const float* __restrict__ pts, const float* __restrict__ cent,
+// A sweep is a chain of dependent loads per vertex (face list -> corner ids -> corner positions), 60 sweeps in a row:
+// the loads of up to VB adjacent faces are issued step by step -- all face ids, then all corner ids and normals, then
+// all corner positions -- instead of walking the faces one by one with three dependent loads each.  The sums keep the
+// face order (same bits as the face-by-face form).
+__global__ __launch_bounds__(256) void vertex_update_kernel(const float* __restrict__ pts, const float* __restrict__ cent,
                                      const int* __restrict__ fv, const float* __restrict__ nrm,
                                      const int* __restrict__ vf, int maxval, const float* __restrict__ dd, int V,
                                      float* __restrict__ out) {
+  constexpr int VB = 8;
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   V3 p = ld3(pts + 3 * (size_t)v);
   V3 s = {0.f, 0.f, 0.f};
   int cnt = 0;
-  for (int a = 0; a < maxval; ++a) {
-    int f = vf[(size_t)v * maxval + a];
-    if (f < 0) continue;
-    ++cnt;
-    V3 n = ld3(nrm + 3 * (size_t)f);
-    V3 c;
-    if (cent != nullptr) {
-      c = ld3(cent + 3 * (size_t)f);
-    } else {
-      V3 t = add(add(ld3(pts + 3 * (size_t)fv[3 * f]), ld3(pts + 3 * (size_t)fv[3 * f + 1])),
-                 ld3(pts + 3 * (size_t)fv[3 * f + 2]));
-      c.x = t.x / 3.0f; c.y = t.y / 3.0f; c.z = t.z / 3.0f;
+  for (int a0 = 0; a0 < maxval; a0 += VB) {
+    int f[VB];
+#pragma unroll
+    for (int i = 0; i < VB; ++i) f[i] = a0 + i < maxval ? vf[(size_t)v * maxval + a0 + i] : -1;
+    int c0[VB], c1[VB], c2[VB];
+    V3 n[VB], c[VB];
+#pragma unroll
+    for (int i = 0; i < VB; ++i) {
+      const int fi = f[i] >= 0 ? f[i] : 0;
+      n[i] = ld3(nrm + 3 * (size_t)fi);
+      if (cent != nullptr) {
+        c[i] = ld3(cent + 3 * (size_t)fi);
+      } else {
+        c0[i] = fv[3 * fi]; c1[i] = fv[3 * fi + 1]; c2[i] = fv[3 * fi + 2];
+      }
     }
-    float d = dot(n, sub(c, p));
-    s = add(s, mul(n, d));
+    if (cent == nullptr) {
+#pragma unroll
+      for (int i = 0; i < VB; ++i) {
+        V3 t = add(add(ld3(pts + 3 * (size_t)c0[i]), ld3(pts + 3 * (size_t)c1[i])), ld3(pts + 3 * (size_t)c2[i]));
+        c[i].x = t.x / 3.0f; c[i].y = t.y / 3.0f; c[i].z = t.z / 3.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VB; ++i) {
+      if (f[i] < 0) continue;
+      ++cnt;
+      float d = dot(n[i], sub(c[i], p));
+      s = add(s, mul(n[i], d));
+    }
   }
   float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
   s = mul(s, inv);
