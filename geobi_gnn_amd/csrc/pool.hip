@@ -788,10 +788,140 @@ __global__ __launch_bounds__(1024) void small_exclusive_scan2_kernel(const int* 
 }
 
 constexpr int64_t kSmallScan = 1 << 18;
+constexpr int64_t kOneBlockScan = 1 << 14;        // up to here the one-block walk is a single step
+
+// Exclusive scan of 16 K .. 256 K ints in ONE launch of several blocks (decoupled look-back): the one-block walk above
+// is bound by a single CU's memory throughput (3.3 us per 16 K ints: 20 us for the 82 K-entry row pointers of the
+// facet level).  Blocks take their index from a ticket (so every predecessor of a block is already running: the
+// look-back cannot wait on a block that has not started), publish (epoch | flag | value) as one 64-bit word -- flag 1:
+// the block's own sum, flag 2: the inclusive prefix up to and including it -- and wave 0 of each block inspects 64
+// predecessors at a time.  The state words carry the call's epoch, so the buffer is never cleared between calls.
+// Library-global state: one scan at a time (every scan of this path runs on the caller's stream, in order).
+__device__ __forceinline__ unsigned long long scan_pack(unsigned epoch, unsigned flag, int value) {
+  return ((unsigned long long)((epoch << 2) | flag) << 32) | (unsigned)value;
+}
+
+__global__ __launch_bounds__(256) void lookback_exclusive_scan_kernel(const int* __restrict__ in, int* __restrict__ out,
+                                                                      int64_t n, unsigned long long* state, int* ticket,
+                                                                      unsigned epoch, int nblocks) {
+  constexpr int EPT = 16, CHUNK = 256 * EPT;
+  __shared__ int s_bid, s_prefix, wsum[4];
+  if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int b = s_bid;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)b * CHUNK + (int64_t)threadIdx.x * EPT;
+  const bool vec = ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0 && i0 + EPT <= n;
+  int v[EPT];
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+      const int4 t = *reinterpret_cast<const int4*>(in + i0 + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) v[q] = (i0 + q < n) ? in[i0 + q] : 0;
+  }
+  int tsum = 0;
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) tsum += v[q];
+  int inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int t = wsum[w];
+    woff += w < wave ? t : 0;
+    total += t;
+  }
+  if (wave == 0) {
+    int prefix = 0;
+    if (b > 0) {
+      if (lane == 0) __hip_atomic_store(state + b, scan_pack(epoch, 1, total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int hi = b - 1; hi >= 0; hi -= 64) {
+        const int pidx = hi - lane;
+        unsigned flag = 2;
+        int val = 0;
+        if (pidx >= 0) {
+          unsigned long long st;
+          int spins = 0;
+          do {
+            st = __hip_atomic_load(state + pidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          } while (((unsigned)(st >> 34) != epoch || ((st >> 32) & 3) == 0) && ++spins < (1 << 26));
+          flag = (unsigned)(st >> 32) & 3;
+          val = (int)(unsigned)st;
+        }
+        const unsigned long long done = __ballot(flag == 2);
+        const int first = done ? __ffsll((long long)done) - 1 : 64;       // nearest predecessor with a full prefix
+        int c = lane <= first ? val : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+        prefix += c;
+        if (done) break;
+      }
+    }
+    if (lane == 0) {
+      __hip_atomic_store(state + b, scan_pack(epoch, 2, prefix + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+      if (b == nblocks - 1) *ticket = 0;                                   // every ticket of this call is taken
+    }
+  }
+  __syncthreads();
+  int ex = s_prefix + woff + inc - tsum;
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+      int4 t;
+      t.x = ex; ex += v[4 * q];
+      t.y = ex; ex += v[4 * q + 1];
+      t.z = ex; ex += v[4 * q + 2];
+      t.w = ex; ex += v[4 * q + 3];
+      *reinterpret_cast<int4*>(out + i0 + 4 * q) = t;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      if (i0 + q < n) out[i0 + q] = ex;
+      ex += v[q];
+    }
+  }
+}
+
+// persistent look-back state (zeroed once; see the kernel)
+static unsigned long long* g_scan_state = nullptr;
+static int* g_scan_ticket = nullptr;
+static unsigned g_scan_epoch = 0;
+
+static hipError_t lookback_scan(const int* in, int* out, int64_t n, hipStream_t s) {
+  if (g_scan_state == nullptr) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 4096 * sizeof(unsigned long long) + 256);
+    if (e != hipSuccess) return e;
+    e = hipMemset(p, 0, 4096 * sizeof(unsigned long long) + 256);
+    if (e != hipSuccess) return e;
+    g_scan_state = (unsigned long long*)p;
+    g_scan_ticket = (int*)((char*)p + 4096 * sizeof(unsigned long long));
+  }
+  g_scan_epoch = (g_scan_epoch + 1) & 0x3fffffffu;
+  if (g_scan_epoch == 0) g_scan_epoch = 1;
+  const int nblocks = cdiv(n, 4096);
+  lookback_exclusive_scan_kernel<<<nblocks, 256, 0, s>>>(in, out, n, g_scan_state, g_scan_ticket, g_scan_epoch, nblocks);
+  return hipGetLastError();
+}
+
 
 static hipError_t exclusive_scan_int(void* temp, size_t& tb, const int* in, int* out, int64_t n, hipStream_t s) {
   if (n <= kSmallScan) {
     if (temp == nullptr) { tb = 16; return hipSuccess; }
+    static const bool lookback = [] { const char* f = getenv("GEOBI_SCAN_LOOKBACK"); return !f || atoi(f) != 0; }();   // A/B knob
+    if (lookback && n > kOneBlockScan) return lookback_scan(in, out, n, s);
     small_exclusive_scan_kernel<<<1, 1024, 0, s>>>(in, out, n);
     return hipGetLastError();
   }
