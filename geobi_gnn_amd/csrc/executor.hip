@@ -138,7 +138,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     w_c[t] = b.take<float>(E);
   }
   const size_t m = b.mark();
-  const size_t mws = match_coarsen_ws_bytes(P), pws = pool_edge_rows_ws_bytes(P);
+  const size_t mws = match_coarsen_ws_bytes(P), pws = pool_edge_rows_ws_bytes_onepass(P, E);
   void* ws_m = b.take<char>(mws);
   void* ws_p = b.take<char>(pws);
   if (!b.ok) return kArenaFull;
@@ -157,7 +157,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   auto run_edges = [&](int t) {
     int32_t* ctr = counters + 4 * t;
     return pool_edge_rows(cnew[t], segptr[t], members[t], in_rp[t], in_cl[t], in_w[t], ctr + 1, P, rowptr_c[t], row_c[t],
-                          col_c[t], w_c[t], ctr + 2, ctr + 3, ws_p, pws, s);
+                          col_c[t], w_c[t], ctr + 2, ctr + 3, ws_p, pws, s, E);     // E bounds both steps' edge counts
   };
   for (int t = 0; t < 2; ++t) {
     GEOBI_TRY(run_match(t, 1));
@@ -453,7 +453,7 @@ extern "C" size_t geobi_net_forward_arena_bytes(int64_t V, int64_t Ev, int64_t F
   // integer arrays of two pooling layers (bounded by the level-0 sizes) and their workspaces
   auto branch = [](int64_t N, int64_t E) {
     return (size_t)N * (4 * 512 + 4 * 2 * 16) + (size_t)E * (4 * 2 * 8) + match_coarsen_ws_bytes(N) +
-           pool_edge_rows_ws_bytes(N) + feast_fwd_ws_bytes(N, 128, 128) + ((size_t)8 << 20) +
+           pool_edge_rows_ws_bytes_onepass(N, E) + feast_fwd_ws_bytes(N, 128, 128) + ((size_t)8 << 20) +
            ((size_t)4 << 20);                     // the branch's packed forward weights (< 2 MB)
   };
   return branch(V, Ev) + branch(F, Ef) + (size_t)F * 12 * 4 + ((size_t)16 << 20);

@@ -539,15 +539,15 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     int* __restrict__ total, int4* __restrict__ rowinfo) {
   const int lane = threadIdx.x & 63;
   const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
+  if (PASS != 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
   if (PASS == 1 && blockIdx.x == 0 && threadIdx.x == 0) *total = rowptr_c[nbound];
   if (A >= nbound) return;
   const int nc = *ncount;
-  if (A >= nc) { if (PASS == 0) cnt[A] = 0; return; }
+  if (A >= nc) { if (PASS != 1) cnt[A] = 0; return; }
   // the members' fine rows: PASS 0 walks segptr -> members -> rowptr (three dependent loads) and leaves the result
   // for PASS 1, whose chain then starts at the row entries
   int r0, d0, r1, d1;
-  if (PASS == 0) {
+  if (PASS != 1) {
     const int ms = segptr[A], me = segptr[A + 1];
     const int m0 = members[ms];
     const int m1 = (me - ms > 1) ? members[ms + 1] : -1;
@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     if (lane == 0) cnt[A] = __popcll(hm);
     return;
   }
+  if (PASS == 2 && lane == 0) cnt[A] = __popcll(hm);
   // run of duplicates starting at a head lane: up to the next head (or the first invalid lane)
   const unsigned long long vm = __ballot(key != 0x7fffffff);
   const int nvalid = __popcll(vm);
@@ -607,10 +608,39 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     if (t < len) sum += (double)v;
   }
   if (head) {
-    const int pos = rowptr_c[A] + __popcll(hm & ((1ull << lane) - 1ull));
-    row_c[pos] = A;
-    col_c[pos] = key;
-    if (w) w_c[pos] = (float)(sum / (double)len);
+    const int t = __popcll(hm & ((1ull << lane) - 1ull));
+    if (PASS == 2) {
+      // one-pass form: the t-th unique entry parks in the t-th slot of the members' own fine rows (there are at most
+      // d0 + d1 of them); pool_edge_compact_kernel moves the rows to their final places once the offsets are known
+      const int pos = t < d0 ? r0 + t : r1 + (t - d0);
+      col_c[pos] = key;                          // (col_c / w_c are the scratch pair here)
+      if (w) w_c[pos] = (float)(sum / (double)len);
+    } else {
+      const int pos = rowptr_c[A] + t;
+      row_c[pos] = A;
+      col_c[pos] = key;
+      if (w) w_c[pos] = (float)(sum / (double)len);
+    }
+  }
+}
+
+// second half of the one-pass form: 16 lanes per coarse node copy its parked entries to rowptr_c[A] ...
+__global__ __launch_bounds__(256) void pool_edge_compact_kernel(const int* __restrict__ ncount, int nbound,
+                                                                const int* __restrict__ rowptr_c,
+                                                                const int4* __restrict__ rowinfo,
+                                                                const int* __restrict__ tcol, const float* __restrict__ tw,
+                                                                int* __restrict__ row_c, int* __restrict__ col_c,
+                                                                float* __restrict__ w_c, int* __restrict__ total) {
+  const int A = (blockIdx.x * 256 + threadIdx.x) >> 4, k = threadIdx.x & 15;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = rowptr_c[nbound];
+  if (A >= nbound || A >= *ncount) return;
+  const int o = rowptr_c[A], c = rowptr_c[A + 1] - o;
+  const int4 ri = rowinfo[A];
+  for (int t = k; t < c; t += 16) {
+    const int src = t < ri.y ? ri.x + t : ri.z + (t - ri.y);
+    row_c[o + t] = A;
+    col_c[o + t] = tcol[src];
+    if (tw) w_c[o + t] = tw[src];
   }
 }
 
@@ -1209,6 +1239,11 @@ int gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float*
   return 0;
 }
 
+// with E (the fine edge count) the workspace also holds the scratch pair of the one-pass form
+size_t pool_edge_rows_ws_bytes_onepass(int64_t nbound, int64_t E) {
+  return pool_edge_rows_ws_bytes(nbound) + 2 * align_up((size_t)E * sizeof(int)) + 256;
+}
+
 size_t pool_edge_rows_ws_bytes(int64_t nbound) {
   return align_up((size_t)(nbound + 1) * sizeof(int)) + align_up(scan_temp_bytes<int>(nbound + 1)) +
          align_up((size_t)nbound * sizeof(int4)) + 512;
@@ -1220,7 +1255,7 @@ size_t pool_edge_rows_ws_bytes(int64_t nbound) {
 int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
                    const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
                    int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
-                   size_t ws_bytes, hipStream_t s) {
+                   size_t ws_bytes, hipStream_t s, int64_t E_fine) {
   GEOBI_REQUIRE(nbound > 0, "pool_edge_rows: empty");
   Arena a(ws, ws_bytes);
   int* cnt = a.take<int>(nbound + 1);
@@ -1229,6 +1264,21 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
   int4* rowinfo = a.take<int4>(nbound);
   GEOBI_REQUIRE(a.ok() && cnt && rowinfo, "pool_edge_rows: workspace too small");
   int blocks = cdiv(nbound, 4);
+  if (E_fine > 0) {
+    // one-pass form (callers that sized the workspace with pool_edge_rows_ws_bytes_onepass): gather + relabel + sort +
+    // merge ONCE, entries parked in scratch, then a short copy pass instead of a second merge
+    int* tcol = a.take<int>(E_fine);
+    float* tw = a.take<float>(E_fine);
+    GEOBI_REQUIRE(a.ok() && tcol && tw, "pool_edge_rows: workspace too small for the one-pass form");
+    pool_edge_rows_kernel<2><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
+                                                     nullptr, nullptr, tcol, tw, overflow, nullptr, rowinfo);
+    GEOBI_LAUNCH_OK();
+    GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
+    pool_edge_compact_kernel<<<cdiv(nbound * 16, 256), 256, 0, s>>>(ncount, (int)nbound, rowptr_c, rowinfo, tcol,
+                                                                    w ? tw : nullptr, row_c, col_c, w_c, count);
+    GEOBI_LAUNCH_OK();
+    return 0;
+  }
   pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
                                                    nullptr, nullptr, nullptr, nullptr, overflow, nullptr, rowinfo);
   GEOBI_LAUNCH_OK();
