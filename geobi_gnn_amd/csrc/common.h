@@ -182,7 +182,8 @@ size_t match_ws_bytes(int64_t N);
 size_t match_coarsen_ws_bytes(int64_t N);
 int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                   int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
-                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s);
+                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s, void* rowinfo_out = nullptr,
+                  bool* rowinfo_made = nullptr);
 int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                      int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
 size_t relabel_ws_bytes(int64_t N);
@@ -212,7 +213,7 @@ size_t pool_edge_rows_ws_bytes_onepass(int64_t nbound, int64_t E);
 int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
                    const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
                    int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
-                   size_t ws_bytes, hipStream_t s, int64_t E_fine = 0);
+                   size_t ws_bytes, hipStream_t s, int64_t E_fine = 0, const void* rowinfo_in = nullptr);
 size_t pool_edge_ws_bytes(int64_t E);
 int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E, int64_t nmax,
               int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, void* ws,

@@ -150,14 +150,19 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   const int32_t* in_rw[2] = {g.row, row_c[0]};
   const float* in_w[2] = {w10, w_c[0]};
   int rounds[2] = {kRounds, kRounds};
+  // the matching leaves each coarse node's member rows for the edge coarsening right behind it
+  void* rowinfo = b.take<char>((size_t)P * 16);
+  if (!b.ok) return kArenaFull;
+  bool rowinfo_ok = false;
   auto run_match = [&](int t, int init) {
     return match_coarsen(in_rp[t], in_cl[t], in_w[t], P, rounds[t], init, state[t], craw[t], cnew[t], segptr[t], members[t],
-                         counters + 4 * t, ws_m, mws, s);
+                         counters + 4 * t, ws_m, mws, s, rowinfo, &rowinfo_ok);
   };
   auto run_edges = [&](int t) {
     int32_t* ctr = counters + 4 * t;
     return pool_edge_rows(cnew[t], segptr[t], members[t], in_rp[t], in_cl[t], in_w[t], ctr + 1, P, rowptr_c[t], row_c[t],
-                          col_c[t], w_c[t], ctr + 2, ctr + 3, ws_p, pws, s, E);     // E bounds both steps' edge counts
+                          col_c[t], w_c[t], ctr + 2, ctr + 3, ws_p, pws, s, E,      // E bounds both steps' edge counts
+                          rowinfo_ok ? rowinfo : nullptr);
   };
   for (int t = 0; t < 2; ++t) {
     GEOBI_TRY(run_match(t, 1));

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void match_lists_scan_kernel(const int* __rest
                                                                const int* __restrict__ bt_rank, const int* __restrict__ bt_offs,
                                                                int nblocks, int N, int* __restrict__ cnew,
                                                                int* __restrict__ count, int* __restrict__ segptr,
-                                                               int* __restrict__ members) {
+                                                               int* __restrict__ members, const int* __restrict__ rowptr,
+                                                               int4* __restrict__ rowinfo) {
   // exclusive prefixes of the block totals (every block recomputes them: <= 4096 ints, L2-resident)
   __shared__ int s_rank[kMaxScanBlocks], s_offs[kMaxScanBlocks];
   __shared__ int s_wave[4];
@@ -306,10 +307,19 @@ __global__ __launch_bounds__(256) void match_lists_scan_kernel(const int* __rest
   cnew[u] = s_rank[rep >> 8] + lrank[rep];
   if (rep == u) {
     const int o = s_offs[u >> 8] + loffs[u];
-    segptr[s_rank[u >> 8] + lrank[u]] = o;
+    const int cid = s_rank[u >> 8] + lrank[u];
+    segptr[cid] = o;
     members[o] = u;
     const int st = state[u];
-    if (st >= 0 && st != u) members[o + 1] = st;
+    const bool pair = st >= 0 && st != u;
+    if (pair) members[o + 1] = st;
+    if (rowinfo != nullptr) {
+      // the members' rows of the matched graph, for the edge coarsening behind this call (it would otherwise walk
+      // segptr -> members -> rowptr, three dependent loads per coarse node)
+      const int r0 = rowptr[u], d0 = rowptr[u + 1] - r0;
+      const int r1 = pair ? rowptr[st] : 0, d1 = pair ? rowptr[st + 1] - r1 : 0;
+      rowinfo[cid] = make_int4(r0, d0, r1, d1);
+    }
   }
   if (u == N - 1) {
     const int nc = s_total[0];
@@ -536,18 +546,28 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ w,
     const int* __restrict__ ncount, int nbound, int* __restrict__ cnt, const int* __restrict__ rowptr_c,
     int* __restrict__ row_c, int* __restrict__ col_c, float* __restrict__ w_c, int* __restrict__ overflow,
-    int* __restrict__ total, int4* __restrict__ rowinfo) {
+    int* __restrict__ total, int4* __restrict__ rowinfo, const int4* __restrict__ rowinfo_in) {
   const int lane = threadIdx.x & 63;
   const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (PASS != 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt[nbound] = 0;     // scan tail: rowptr_c[nbound] = total
   if (PASS == 1 && blockIdx.x == 0 && threadIdx.x == 0) *total = rowptr_c[nbound];
   if (A >= nbound) return;
+  // requested before the coarse count is known (entries past it are never read back): one dependent load less
+  int4 ri_in = make_int4(0, 0, 0, 0);
+  if (PASS == 2 && rowinfo_in != nullptr) ri_in = rowinfo_in[A];
   const int nc = *ncount;
   if (A >= nc) { if (PASS != 1) cnt[A] = 0; return; }
   // the members' fine rows: PASS 0 walks segptr -> members -> rowptr (three dependent loads) and leaves the result
   // for PASS 1, whose chain then starts at the row entries
   int r0, d0, r1, d1;
-  if (PASS != 1) {
+  if (PASS == 2 && rowinfo_in != nullptr) {
+    const int4 ri = ri_in;
+    r0 = ri.x; d0 = ri.y; r1 = ri.z; d1 = ri.w;
+    if (lane == 0) {
+      rowinfo[A] = ri;
+      if (d0 + d1 > 64) atomicOr(overflow, 1);
+    }
+  } else if (PASS != 1) {
     const int ms = segptr[A], me = segptr[A + 1];
     const int m0 = members[ms];
     const int m1 = (me - ms > 1) ? members[ms + 1] : -1;
@@ -568,10 +588,26 @@ __global__ __launch_bounds__(256) void pool_edge_rows_kernel(
     int k = cnew[col[e]];
     if (k != A) { key = k; val = w ? w[e] : 0.f; }
   }
-  // bitonic sort, ascending by key; rows of up to 32 entries (the usual case: two mesh rows) skip the 64-wide merge
+  // bitonic sort, ascending by key; rows of up to 32 entries (the usual case: two mesh rows) skip the 64-wide merge.
+  // Partner exchange at distance 1, 2, 4, 8 by DPP lane permutes (quad_perm, row_shl/shr:4, row_ror:8) -- 14 of the 15
+  // stages of the 32-wide sort; a wave is a chain of ~20 dependent exchanges, and an LDS-crossbar permute costs ~10x
+  // a DPP move in latency.  Every lane of the wave is active here (waves past the coarse count left as a whole).
+  auto xchg = [&](int v, int j) -> int {
+    switch (j) {
+      case 1: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+      case 2: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+      case 4: {
+        const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, true);       // row_shl:4  lane i <- i + 4
+        const int dn = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);       // row_shr:4  lane i <- i - 4
+        return (lane & 4) ? dn : up;
+      }
+      case 8: return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);          // row_ror:8 = xor 8 in a row
+      default: return __shfl_xor(v, j, 64);
+    }
+  };
   auto stage = [&](int k, int j) {
-    const int pk = __shfl_xor(key, j, 64);
-    const float pv = __shfl_xor(val, j, 64);
+    const int pk = xchg(key, j);
+    const float pv = __int_as_float(xchg(__float_as_int(val), j));
     const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
     const bool take = keep_min ? (pk < key) : (pk > key);
     if (take) { key = pk; val = pv; }
@@ -1063,7 +1099,7 @@ size_t match_coarsen_ws_bytes(int64_t N) {
 // produce, 6 launches fewer).  counters[0] = undecided nodes, counters[1] = coarse node count.
 int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                   int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
-                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s) {
+                  int32_t* counters, void* ws, size_t ws_bytes, hipStream_t s, void* rowinfo_out, bool* rowinfo_made) {
   GEOBI_REQUIRE(N > 0 && rounds > 0, "match_coarsen: empty graph or no rounds");
   Arena a(ws, ws_bytes);
   int* prop0 = a.take<int>(N);
@@ -1088,10 +1124,12 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
     match_commit_scan_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz, bt_rank, bt_offs);
     GEOBI_LAUNCH_OK();
     match_lists_scan_kernel<<<blocks, 256, 0, s>>>(state, cluster_final, flag, sz, bt_rank, bt_offs, blocks, (int)N, cnew,
-                                                   counters + 1, segptr, members);
+                                                   counters + 1, segptr, members, rowptr, (int4*)rowinfo_out);
     GEOBI_LAUNCH_OK();
+    if (rowinfo_made) *rowinfo_made = rowinfo_out != nullptr;
     return 0;
   }
+  if (rowinfo_made) *rowinfo_made = false;
   match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
   GEOBI_LAUNCH_OK();
   if (N + 1 <= kSmallScan) {
@@ -1255,7 +1293,7 @@ size_t pool_edge_rows_ws_bytes(int64_t nbound) {
 int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
                    const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
                    int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
-                   size_t ws_bytes, hipStream_t s, int64_t E_fine) {
+                   size_t ws_bytes, hipStream_t s, int64_t E_fine, const void* rowinfo_in) {
   GEOBI_REQUIRE(nbound > 0, "pool_edge_rows: empty");
   Arena a(ws, ws_bytes);
   int* cnt = a.take<int>(nbound + 1);
@@ -1271,7 +1309,8 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
     float* tw = a.take<float>(E_fine);
     GEOBI_REQUIRE(a.ok() && tcol && tw, "pool_edge_rows: workspace too small for the one-pass form");
     pool_edge_rows_kernel<2><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                     nullptr, nullptr, tcol, tw, overflow, nullptr, rowinfo);
+                                                     nullptr, nullptr, tcol, tw, overflow, nullptr, rowinfo,
+                                                     (const int4*)rowinfo_in);
     GEOBI_LAUNCH_OK();
     GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
     pool_edge_compact_kernel<<<cdiv(nbound * 16, 256), 256, 0, s>>>(ncount, (int)nbound, rowptr_c, rowinfo, tcol,
@@ -1280,11 +1319,11 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
     return 0;
   }
   pool_edge_rows_kernel<0><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   nullptr, nullptr, nullptr, nullptr, overflow, nullptr, rowinfo);
+                                                   nullptr, nullptr, nullptr, nullptr, overflow, nullptr, rowinfo, nullptr);
   GEOBI_LAUNCH_OK();
   GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
   pool_edge_rows_kernel<1><<<blocks, 256, 0, s>>>(cnew, segptr, members, rowptr, col, w, ncount, (int)nbound, cnt,
-                                                   rowptr_c, row_c, col_c, w_c, overflow, count, rowinfo);
+                                                   rowptr_c, row_c, col_c, w_c, overflow, count, rowinfo, nullptr);
   GEOBI_LAUNCH_OK();
   return 0;
 }
