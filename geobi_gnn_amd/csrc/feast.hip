@@ -867,7 +867,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   // One kernel for the first half of the backward when the layer reads <= 64 channels (GEOBI_ROWPASS_FUSED=0: A/B):
   // g, dz (LDS only), row pass.  Otherwise three: leaky-relu backward, dz GEMM (dz [N, 9 Cin] through HBM), row pass.
   static const bool rp_fused_on = [] { const char* f = getenv("GEOBI_ROWPASS_FUSED"); return !f || atoi(f) != 0; }();
-  const bool rp_fused = fused && rp_fused_on && feast_rowpass_fused_supported(Cin, Cb);
+  const bool rp_fused = fused && rp_fused_on && feast_rowpass_fused_supported(Cin, Cb, Cout);
   const float* g = gout;
   if (slope != 1.0f) g = b.g;
   if (rp_fused) {

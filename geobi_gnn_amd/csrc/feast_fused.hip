@@ -487,6 +487,233 @@ __global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
                               tile * RT + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same first half of the backward for layers reading 128 channels.  A [32][9 x 128] dz tile does not fit, and the
+// dz GEMM of these layers (gemm_nn) was writing 4.6 KB per node to HBM for the row pass to read back.  Here the
+// channels go in four chunks of 32: per chunk the matrix phase forms dz[32 nodes][9 heads x 32 channels] in LDS (one
+// 32-column MFMA tile per head), the row pass adds that chunk's share to the nine dot products of every item (in-edge
+// or self loop), and the softmax backward runs once all four chunks are in.  The partial dot products of a node's
+// first 16 items wait in registers; nodes with more items park the rest in the rows they overwrite at the end anyway
+// (dl rows of the edges, the node's dcs row for the self loop).
+template <int COUT>
+__global__ __launch_bounds__(512, 4) void feast_rowpass_fused128_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
+    const float* __restrict__ gout, const float* __restrict__ out_act, float slope, const float* __restrict__ Wf,
+    float* __restrict__ g_out, float* __restrict__ dl, float* __restrict__ dpn, float* __restrict__ dcs, int ld_dcs) {
+  constexpr int C = 128, CCH = 32, NCC = C / CCH;
+  constexpr int KC = H * CCH;                    // dz columns per chunk: head h at [32 h, 32 h + 32)
+  constexpr int LDZ = KC + 4;                    // + 4: the four node groups of a wave read distinct bank quads
+  constexpr int GL = COUT + 4;
+  constexpr int NQ = CCH / 4;                    // 16-B pieces per head and chunk
+  constexpr int NPIECE = H * NQ, NSLOT = (NPIECE + G - 1) / G;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_g = smem;                             // [32][GL]
+  float* s_z = smem + TN * GL;                   // [32][LDZ]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = xcd_block(blockIdx.x, gridDim.x);
+  if (tile * TN >= N) return;
+
+  // ---- g tile (as in the kernel above)
+  {
+    constexpr int Q = COUT / 4;
+    for (int i = threadIdx.x; i < TN * Q; i += 512) {
+      const int r = i / Q, c4 = (i - r * Q) * 4;
+      const int gn = tile * TN + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gn < N) {
+        v = *reinterpret_cast<const float4*>(gout + (size_t)gn * COUT + c4);
+        if (out_act != nullptr) {
+          const float4 o = *reinterpret_cast<const float4*>(out_act + (size_t)gn * COUT + c4);
+          v.x = o.x > 0.f ? v.x : v.x * slope; v.y = o.y > 0.f ? v.y : v.y * slope;
+          v.z = o.z > 0.f ? v.z : v.z * slope; v.w = o.w > 0.f ? v.w : v.w * slope;
+          *reinterpret_cast<float4*>(g_out + (size_t)gn * COUT + c4) = v;
+        }
+      }
+      *reinterpret_cast<float4*>(s_g + r * GL + c4) = v;
+    }
+  }
+
+  // ---- row-pass roles: group of 16 lanes <-> node, lane k <-> one item per chunk of 16 items
+  const int g = lane / G, k = lane % G;
+  const int nl = wave * NPW + g;
+  const int node = tile * TN + nl;
+  const bool valid = node < N;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int deg = valid ? rowptr[ns + 1] - rs : -1;            // items = deg edges + the self loop; none if invalid
+  const int Cb = C - Ca;
+  float* selfrow = dcs + (size_t)ns * ld_dcs;                  // where a self loop outside the first 16 items parks
+  float sv0[H];                                                // partial dot products of the node's first 16 items
+#pragma unroll
+  for (int h = 0; h < H; ++h) sv0[h] = 0.f;
+  const int j0 = k < deg ? col[rs + k] : ns;                   // the first 16 items' neighbour, kept across the chunks
+  __syncthreads();
+
+  const int hf = lane >> 5, l31 = lane & 31;
+  constexpr int NKB = COUT / 8, HB = 4;
+  static_assert(NKB % HB == 0, "whole weight batches");
+  static_for<0, NCC>([&](auto cci) {
+    constexpr int cc = decltype(cci)::value;
+    // ---- matrix phase: head h's 32 columns of this channel chunk = dz tile h; wave w takes tile w, wave 0 also tile 8
+    {
+      const float* arow = s_g + l31 * GL + 4 * hf;
+#pragma unroll
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        const int t = wave + 8 * rnd;
+        if (t < H) {                                           // wave-uniform
+          const float* brow = Wf + (size_t)(t * C + cc * CCH + l31) * COUT + 4 * hf;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int b0 = 0; b0 < NKB; b0 += HB) {
+            float4 wv[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) wv[u] = *reinterpret_cast<const float4*>(brow + 8 * (b0 + u));
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+              const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + t * 32 + l31] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- this chunk's share of the dot products, lane = item; every lane of a group runs the FMAs (row broadcasts)
+    {
+      float dzr[NSLOT][4];
+      const float* zrow = s_z + nl * LDZ;
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) {
+        const int pidx = sl * G + k;
+        if (pidx < NPIECE) load_piece<4>(zrow + pidx * 4, dzr[sl]);
+        else { dzr[sl][0] = 0.f; dzr[sl][1] = 0.f; dzr[sl][2] = 0.f; dzr[sl][3] = 0.f; }
+      }
+      for (int base = 0; base <= deg; base += G) {
+        const int idx = base + k;
+        const bool real = idx < deg, self = idx == deg;
+        const int e = rs + idx;
+        const int j = base == 0 ? j0 : (real ? col[e] : ns);
+        const float* src = (cc * CCH < Ca) ? xa + (size_t)j * Ca + cc * CCH : xb + (size_t)j * Cb + (cc * CCH - Ca);
+        float* park = real ? dl + (size_t)e * HP : selfrow;
+        float sv[H];
+        if (base == 0) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) sv[h] = sv0[h];
+        } else {
+          float t[HP];
+#pragma unroll
+          for (int h = 0; h < HP; ++h) t[h] = 0.f;
+          if (cc > 0 && (real || self)) load_row<HP>(park, t);
+#pragma unroll
+          for (int h = 0; h < H; ++h) sv[h] = t[h];
+        }
+        static_for<0, NQ / 4>([&](auto bi) {
+          constexpr int q0 = decltype(bi)::value * 4;
+          float xj[4][4];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) load_piece<4>(src + (q0 + qd) * 4, xj[qd]);
+          static_for<0, 4>([&](auto qi) {
+            constexpr int qd = decltype(qi)::value;
+            static_for<0, H>([&](auto hi) {
+              constexpr int h = decltype(hi)::value;
+              constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
+              fmac_bcast<owner, 4>(sv[h], dzr[sl], xj[qd]);
+            });
+          });
+        });
+        if (base == 0) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) sv0[h] = sv[h];
+        } else if (real || self) {
+          float4* pr = reinterpret_cast<float4*>(park);
+          pr[0] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+          pr[1] = make_float4(sv[4], sv[5], sv[6], sv[7]);
+          pr[2] = make_float4(sv[8], 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    if constexpr (cc + 1 < NCC) __syncthreads();               // the next chunk overwrites the dz tile
+  });
+
+  // ---- softmax backward with the complete dot products
+  float cc9[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) cc9[h] = cvec[h];
+  const float invd = 1.0f / (float)(deg + 1);
+  float dsum[H], d[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { dsum[h] = 0.f; d[h] = 0.f; }
+  bool self = false;
+  for (int base = 0; base <= deg; base += G) {
+    const int idx = base + k;
+    const bool real = idx < deg;
+    self = idx == deg;
+    const int e = rs + idx;
+    float sv[H];
+    if (base == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) sv[h] = sv0[h];
+    } else {
+      float t[HP];
+#pragma unroll
+      for (int h = 0; h < HP; ++h) t[h] = 0.f;
+      if (real || self) load_row<HP>(real ? dl + (size_t)e * HP : selfrow, t);
+#pragma unroll
+      for (int h = 0; h < H; ++h) sv[h] = t[h];
+    }
+    float q[H];
+    if (real) {
+      const int j = base == 0 ? j0 : col[e];
+      float pc[H], pn[H];
+      load_hp(p + (size_t)ns * HP, pc);
+      load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc9[h];
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = cc9[h];
+    }
+    softmax9(q);
+    float tq = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) tq = fmaf(q[h], sv[h], tq);
+#pragma unroll
+    for (int h = 0; h < H; ++h) d[h] = q[h] * (sv[h] - tq) * invd;
+    if (real) {
+      float4* drow = reinterpret_cast<float4*>(dl + (size_t)e * HP);
+      drow[0] = make_float4(d[0], d[1], d[2], d[3]);
+      drow[1] = make_float4(d[4], d[5], d[6], d[7]);
+      drow[2] = make_float4(d[8], 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; ++h) dsum[h] += d[h];
+    }
+  }
+  float dself[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dsum[h] = group_allreduce<G>(dsum[h]);
+    dself[h] = group_allreduce<G>(self ? d[h] : 0.f);
+  }
+  if (!valid || k != 0) return;
+  float4* a4 = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
+  a4[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
+  a4[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
+  a4[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
+  float4* bq = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
+  bq[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
+  bq[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
+  bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
+}
+
 // Packed weights of the forward:  Bp[kb][half][col][s] = lin.weight[h * Cout + col, kin] for k = 8 kb + 4 half + s
 // = h * Cin + kin (zero for k >= 9 Cin or col >= Cout), NP = padded column count (multiple of 32).
 __global__ void pack_fused_fwd_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int KD, int NP,
@@ -675,8 +902,34 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
 }
 }  // namespace
 
-// split inputs: the row is read in batches of 16 channels, so the first part must end on such a boundary
-bool feast_rowpass_fused_supported(int Cin, int Cb) {
+namespace {
+template <int COUT>
+int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
+                            const int* rowptr, const int* col, int N, const float* gout, const float* out_act,
+                            float slope, const float* Wf, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
+                            hipStream_t s) {
+  constexpr size_t lds = ((size_t)TN * (COUT + 4) + (size_t)TN * (H * 32 + 4)) * sizeof(float);
+  static_assert(lds <= 81920, "two workgroups per CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused128_kernel<COUT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  feast_rowpass_fused128_kernel<COUT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+      xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn, dcs, ld_dcs);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+}  // namespace
+
+// split inputs: the row is read in batches of 16 channels (32 at 128 channels), so the first part must end on such a
+// boundary; 128 channels: Cout 64 or 128 (GEOBI_ROWPASS_FUSED128=0: the GEMM + standalone row pass)
+bool feast_rowpass_fused_supported(int Cin, int Cb, int Cout) {
+  if (Cin == 128) {
+    static const bool on = [] { const char* f = getenv("GEOBI_ROWPASS_FUSED128"); return !f || atoi(f) != 0; }();   // A/B knob
+    return on && (Cout == 64 || Cout == 128) && (Cb == 0 || (Cin - Cb) % 32 == 0);
+  }
   return Cin <= 64 && (Cb == 0 || (Cin >= 32 && (Cin - Cb) % 16 == 0));
 }
 
@@ -692,6 +945,16 @@ int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const
     case 64: return launch_rowpass_fused<C_, L_, 64>(GEOBI_RP_ARGS);                     \
     case 128: return launch_rowpass_fused<C_, L_, 128>(GEOBI_RP_ARGS);                   \
     default: return set_error("feast fused row pass: unsupported Cout=%d", Cout);        \
+  }
+  if (Cin == 128) {
+    GEOBI_REQUIRE(LC == 0, "feast fused row pass: per-edge logits at 128 channels");
+    if (Cout == 64)
+      return launch_rowpass_fused128<64>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn,
+                                         dcs, ld_dcs, s);
+    if (Cout == 128)
+      return launch_rowpass_fused128<128>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn,
+                                          dcs, ld_dcs, s);
+    return set_error("feast fused row pass: unsupported Cout=%d at 128 input channels", Cout);
   }
   switch (Cin * 100 + LC) {
     case 600: GEOBI_RP_COUT(6, 0)
