@@ -174,6 +174,11 @@ def test_feast_conv_directed_graph_and_isolated_nodes(dev):
     for fused in (True, False):
         errs = _run_feast(dev, 32, 64, ei, n, 0.2, False, seed=11, fused=fused)
         assert max(errs.values()) < TOL, (fused, errs)
+    # 128 input channels: the fused backward keeps the partial dot products of a node's first 16 items in registers and
+    # parks the rest (here up to 200 items of the hub, and its self loop) in the rows it overwrites at the end
+    for cout, split in ((64, False), (128, True)):
+        errs = _run_feast(dev, 128, cout, ei, n, 0.2, split, seed=13 + cout, fused=True)
+        assert max(errs.values()) < TOL, (cout, split, errs)
 
 
 def test_feast_conv_large_logits(dev):
