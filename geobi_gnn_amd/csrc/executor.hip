@@ -37,6 +37,7 @@ struct PoolSave {
   const int32_t *seg[2] = {nullptr, nullptr}, *segptr[2] = {nullptr, nullptr};
   const int32_t* arg[2] = {nullptr, nullptr};
   const int32_t *segptr12 = nullptr, *members12 = nullptr;     // fine -> coarse inverse lists (unpool backward)
+  const int32_t* unpool = nullptr;                             // composed fine -> coarse index (max-pool backward)
 };
 struct BranchTape {
   Level L[3];
@@ -207,17 +208,17 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   const int64_t R2 = (int64_t)h[5] - (P - R1), E2 = h[6];     // the padding nodes came back as singletons
   if (E1 <= 0 || E2 <= 0 || R1 <= 0 || R2 <= 0) return kFallback;
   // ---- features with exact sizes
-  float* x1 = b.take<float>((size_t)R1 * C);
   float* x2 = b.take<float>((size_t)R2 * C);
   int32_t* unpool = b.take<int32_t>(P);
-  int32_t *arg1 = nullptr, *arg2 = nullptr, *segptr12 = nullptr, *members12 = nullptr, *pos_rev = nullptr;
+  int32_t *arg2 = nullptr, *segptr12 = nullptr, *members12 = nullptr, *pos_rev = nullptr;
   if (save) {       // training: arg-max rows, the composed inverse lists and the coarse level's reverse-edge index stay
-    arg1 = b.take<int32_t>((size_t)R1 * C); arg2 = b.take<int32_t>((size_t)R2 * C);
+    arg2 = b.take<int32_t>((size_t)R2 * C);
     segptr12 = b.take<int32_t>(R2 + 1); members12 = b.take<int32_t>(P);
     pos_rev = b.take<int32_t>(E2);
   }
   const size_t m2 = b.mark();
-  if (!save) { arg1 = b.take<int32_t>((size_t)R1 * C); arg2 = arg1; }
+  if (!save) arg2 = b.take<int32_t>((size_t)R2 * C);
+  float* x1 = pool_mean ? b.take<float>((size_t)R1 * C) : nullptr;      // the mean needs the step-one rows
   const size_t cws = segment_pairs_ws_bytes(R2);
   void* ws_c = save ? b.take<char>(cws) : nullptr;
   if (!b.ok) return kArenaFull;
@@ -225,8 +226,9 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     GEOBI_TRY(segment_sum(x, C, segptr[0], members[0], R1, 1, x1, s));
     GEOBI_TRY(segment_sum(x1, C, segptr[1], members[1], R2, 1, x2, s));
   } else {
-    GEOBI_TRY(segment_max_fwd(x, C, segptr[0], members[0], R1, x1, arg1, s));
-    GEOBI_TRY(segment_max_fwd(x1, C, segptr[1], members[1], R2, x2, arg2, s));
+    // both matching steps in one pass over the composed segments: same values and the same arg-max routing as two
+    // segment_max passes (pool.hip), the step-one maxima are never written
+    GEOBI_TRY(segment_max2_fwd(x, C, segptr[0], members[0], segptr[1], members[1], R2, x2, arg2, s));
   }
   compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
   GEOBI_LAUNCH_OK();
@@ -235,7 +237,8 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     GEOBI_TRY(csr_reverse_index(rowptr_c[1], row_c[1], col_c[1], E2, pos_rev, nullptr, s));
     save->C = C; save->pool_mean = pool_mean; save->P = P; save->R1 = R1; save->R2 = R2;
     save->seg[0] = cnew[0]; save->seg[1] = cnew[1]; save->segptr[0] = segptr[0]; save->segptr[1] = segptr[1];
-    save->arg[0] = arg1; save->arg[1] = arg2; save->segptr12 = segptr12; save->members12 = members12;
+    save->arg[0] = nullptr; save->arg[1] = arg2; save->segptr12 = segptr12; save->members12 = members12;
+    save->unpool = unpool;
   }
   b.release(m2);
   r.coarse.pos_rev = pos_rev;
@@ -339,15 +342,14 @@ int conv_bwd(Bump& b, const ConvSave& c, const geobi_conv_params_t& grad, const 
 
 // pooling backward: gradient of the pooled features [R2, C] -> gradient of the layer input [P, C]
 int pool_bwd(Bump& b, const PoolSave& p, const float* g2, float** gx, hipStream_t s) {
-  float* g1 = b.take<float>((size_t)p.R1 * p.C);
+  float* g1 = p.pool_mean ? b.take<float>((size_t)p.R1 * p.C) : nullptr;
   float* g0 = b.take<float>((size_t)p.P * p.C);
   if (!b.ok) return kArenaFull;
   if (p.pool_mean) {
     GEOBI_TRY(segment_mean_bwd(g2, p.seg[1], p.segptr[1], p.C, p.R1, g1, s));
     GEOBI_TRY(segment_mean_bwd(g1, p.seg[0], p.segptr[0], p.C, p.P, g0, s));
   } else {
-    GEOBI_TRY(segment_max_bwd(g2, p.arg[1], p.seg[1], p.C, p.R2, p.R1, g1, s));
-    GEOBI_TRY(segment_max_bwd(g1, p.arg[0], p.seg[0], p.C, p.R1, p.P, g0, s));
+    GEOBI_TRY(segment_max2_bwd(g2, p.arg[1], p.unpool, p.C, p.R2, p.P, g0, s));
   }
   *gx = g0;
   return 0;

@@ -445,6 +445,51 @@ __global__ void segment_max_fwd_kernel(const float* __restrict__ x, int C, const
   arg[t] = bi;
 }
 
+// Max over the composition of two clusterings (a pooling layer's two matching steps) in ONE pass: segment c of the
+// second step = concatenation, in order, of the first-step segments of its members.  The running maximum keeps the
+// first maximum in that order -- the element the two-step form (max of the step-one maxima, first maximum at each
+// step) routes to -- so out and the backward's routing are identical to two segment_max passes; the step-one
+// maxima are never materialised.  arg12 holds the FINE row of the maximum.
+__global__ void segment_max2_fwd_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr1,
+                                        const int* __restrict__ members1, const int* __restrict__ segptr2,
+                                        const int* __restrict__ members2, int nseg2, float* __restrict__ out,
+                                        int* __restrict__ arg12) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nseg2 * C) return;
+  const int sidx = (int)(t / C), c = (int)(t % C);
+  float best = 0.f;
+  int bi = -1;
+  for (int e2 = segptr2[sidx]; e2 < segptr2[sidx + 1]; ++e2) {
+    const int m = members2[e2];
+    float mb = 0.f;                               // the step-one maximum of segment m and its first position
+    int mi = -1;
+    for (int e1 = segptr1[m]; e1 < segptr1[m + 1]; ++e1) {
+      const int f = members1[e1];
+      const float v = x[(size_t)f * C + c];
+      if (mi < 0 || v > mb) { mb = v; mi = f; }
+    }
+    if (mi >= 0 && (bi < 0 || mb > best)) { best = mb; bi = mi; }
+  }
+  out[t] = best;
+  arg12[t] = bi;
+}
+
+// gather form of its backward: fine row n receives the gradient of its composed segment where it was the arg-max
+__global__ void segment_max2_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg12,
+                                        const int* __restrict__ seg12, int C, int64_t total, int nseg2,
+                                        float* __restrict__ gx) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int n = (int)(t / C), c = (int)(t % C);
+  const int sg = seg12[n];
+  float v = 0.f;
+  if (sg >= 0 && sg < nseg2) {
+    const size_t o = (size_t)sg * C + c;
+    if (arg12[o] == n) v = gout[o];
+  }
+  gx[t] = v;
+}
+
 // gather form: fine row n receives the gradient of its segment where it was the arg-max (every
 // element of gx is written exactly once -> no zero-fill pass)
 __global__ void segment_max_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg,
@@ -1250,6 +1295,23 @@ int segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, i
                     float* gx, hipStream_t s) {
   if (n_fine <= 0) return 0;
   segment_max_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, arg, seg, C, n_fine * C, (int)nseg, gx);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_max2_fwd(const float* x, int C, const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                     const int32_t* members2, int64_t nseg2, float* out, int32_t* arg12, hipStream_t s) {
+  if (nseg2 <= 0) return 0;
+  segment_max2_fwd_kernel<<<cdiv(nseg2 * C, 256), 256, 0, s>>>(x, C, segptr1, members1, segptr2, members2, (int)nseg2, out,
+                                                              arg12);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_max2_bwd(const float* gout, const int32_t* arg12, const int32_t* seg12, int C, int64_t nseg2, int64_t n_fine,
+                     float* gx, hipStream_t s) {
+  if (n_fine <= 0) return 0;
+  segment_max2_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, arg12, seg12, C, n_fine * C, (int)nseg2, gx);
   GEOBI_LAUNCH_OK();
   return 0;
 }
