@@ -201,6 +201,8 @@ int segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const i
                         int32_t* members12, void* ws, size_t ws_bytes, hipStream_t s);
 int segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, float* out,
                     int32_t* arg, hipStream_t s);
+int segment_sum2(const float* x, int C, const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                 const int32_t* members2, int64_t nseg2, float* out, hipStream_t s);
 int segment_max2_fwd(const float* x, int C, const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
                      const int32_t* members2, int64_t nseg2, float* out, int32_t* arg12, hipStream_t s);
 int segment_max2_bwd(const float* gout, const int32_t* arg12, const int32_t* seg12, int C, int64_t nseg2, int64_t n_fine,

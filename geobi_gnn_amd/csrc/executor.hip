@@ -36,7 +36,7 @@ struct PoolSave {
   int64_t P = 0, R1 = 0, R2 = 0;
   const int32_t *seg[2] = {nullptr, nullptr}, *segptr[2] = {nullptr, nullptr};
   const int32_t* arg[2] = {nullptr, nullptr};
-  const int32_t *segptr12 = nullptr, *members12 = nullptr;     // fine -> coarse inverse lists (unpool backward)
+  const int32_t* members[2] = {nullptr, nullptr};              // with segptr: the inverse lists of the two steps
   const int32_t* unpool = nullptr;                             // composed fine -> coarse index (max-pool backward)
 };
 struct BranchTape {
@@ -210,17 +210,14 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   // ---- features with exact sizes
   float* x2 = b.take<float>((size_t)R2 * C);
   int32_t* unpool = b.take<int32_t>(P);
-  int32_t *arg2 = nullptr, *segptr12 = nullptr, *members12 = nullptr, *pos_rev = nullptr;
-  if (save) {       // training: arg-max rows, the composed inverse lists and the coarse level's reverse-edge index stay
+  int32_t *arg2 = nullptr, *pos_rev = nullptr;
+  if (save) {       // training: arg-max rows and the coarse level's reverse-edge index stay
     arg2 = b.take<int32_t>((size_t)R2 * C);
-    segptr12 = b.take<int32_t>(R2 + 1); members12 = b.take<int32_t>(P);
     pos_rev = b.take<int32_t>(E2);
   }
   const size_t m2 = b.mark();
   if (!save) arg2 = b.take<int32_t>((size_t)R2 * C);
   float* x1 = pool_mean ? b.take<float>((size_t)R1 * C) : nullptr;      // the mean needs the step-one rows
-  const size_t cws = segment_pairs_ws_bytes(R2);
-  void* ws_c = save ? b.take<char>(cws) : nullptr;
   if (!b.ok) return kArenaFull;
   if (pool_mean) {
     GEOBI_TRY(segment_sum(x, C, segptr[0], members[0], R1, 1, x1, s));
@@ -233,11 +230,10 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
   GEOBI_LAUNCH_OK();
   if (save) {
-    GEOBI_TRY(segment_csr_compose(segptr[0], members[0], segptr[1], members[1], R2, P, segptr12, members12, ws_c, cws, s));
     GEOBI_TRY(csr_reverse_index(rowptr_c[1], row_c[1], col_c[1], E2, pos_rev, nullptr, s));
     save->C = C; save->pool_mean = pool_mean; save->P = P; save->R1 = R1; save->R2 = R2;
     save->seg[0] = cnew[0]; save->seg[1] = cnew[1]; save->segptr[0] = segptr[0]; save->segptr[1] = segptr[1];
-    save->arg[0] = nullptr; save->arg[1] = arg2; save->segptr12 = segptr12; save->members12 = members12;
+    save->arg[0] = nullptr; save->arg[1] = arg2; save->members[0] = members[0]; save->members[1] = members[1];
     save->unpool = unpool;
   }
   b.release(m2);
@@ -373,10 +369,13 @@ int gnn_backward(Bump& b, const BranchTape& t, const geobi_gnn_params_t& grad, c
   if (!b.ok) return kArenaFull;
   GEOBI_TRY(conv_bwd(b, t.conv[7], grad.conv[7], g_out, g_x0, g_r3, accumulate, s));
   GEOBI_TRY(conv_bwd(b, t.conv[6], grad.conv[6], g_r3, g_up1, nullptr, accumulate, s));
-  GEOBI_TRY(segment_sum(g_up1, 64, t.pool[0].segptr12, t.pool[0].members12, N1, 0, g_x1b, s));
+  // unpool backward: sums over the composed segments, walked through the two steps' lists (no composed list is built)
+  GEOBI_TRY(segment_sum2(g_up1, 64, t.pool[0].segptr[0], t.pool[0].members[0], t.pool[0].segptr[1], t.pool[0].members[1],
+                         N1, g_x1b, s));
   GEOBI_TRY(conv_bwd(b, t.conv[5], grad.conv[5], g_x1b, g_x1, g_r1, accumulate, s));
   GEOBI_TRY(conv_bwd(b, t.conv[4], grad.conv[4], g_r1, g_up2, nullptr, accumulate, s));
-  GEOBI_TRY(segment_sum(g_up2, 128, t.pool[1].segptr12, t.pool[1].members12, N2, 0, g_x2, s));
+  GEOBI_TRY(segment_sum2(g_up2, 128, t.pool[1].segptr[0], t.pool[1].members[0], t.pool[1].segptr[1], t.pool[1].members[1],
+                         N2, g_x2, s));
   GEOBI_TRY(conv_bwd(b, t.conv[3], grad.conv[3], g_x2, g_x2a, nullptr, accumulate, s));
   GEOBI_TRY(conv_bwd(b, t.conv[2], grad.conv[2], g_x2a, g_x2p, nullptr, accumulate, s));
   float* g_pool = nullptr;

@@ -519,6 +519,22 @@ __global__ void segment_sum_kernel(const float* __restrict__ x, int C, const int
   out[t] = s;
 }
 
+// Sum over the composition of two clusterings, the members walked in the order the composed list (compose_fill_kernel)
+// would hold them -- same sums bit for bit, without building that list.
+__global__ void segment_sum2_kernel(const float* __restrict__ x, int C, const int* __restrict__ segptr1,
+                                    const int* __restrict__ members1, const int* __restrict__ segptr2,
+                                    const int* __restrict__ members2, int nseg2, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nseg2 * C) return;
+  const int sidx = (int)(t / C), c = (int)(t % C);
+  float s = 0.f;
+  for (int e2 = segptr2[sidx]; e2 < segptr2[sidx + 1]; ++e2) {
+    const int m = members2[e2];
+    for (int e1 = segptr1[m]; e1 < segptr1[m + 1]; ++e1) s += x[(size_t)members1[e1] * C + c];
+  }
+  out[t] = s;
+}
+
 __global__ void segment_mean_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ seg,
                                         const int* __restrict__ segptr, int C, int64_t total,
                                         float* __restrict__ gx) {
@@ -1320,6 +1336,14 @@ int segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* mem
                 float* out, hipStream_t s) {
   if (nseg <= 0) return 0;
   segment_sum_kernel<<<cdiv(nseg * C, 256), 256, 0, s>>>(x, C, segptr, members, (int)nseg, mean, out);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int segment_sum2(const float* x, int C, const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
+                 const int32_t* members2, int64_t nseg2, float* out, hipStream_t s) {
+  if (nseg2 <= 0) return 0;
+  segment_sum2_kernel<<<cdiv(nseg2 * C, 256), 256, 0, s>>>(x, C, segptr1, members1, segptr2, members2, (int)nseg2, out);
   GEOBI_LAUNCH_OK();
   return 0;
 }
