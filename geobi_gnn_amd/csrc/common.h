@@ -175,7 +175,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
               hipStream_t s);
 // pool.hip
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
-                    float* w_out, hipStream_t s);
+                    float* w_out, hipStream_t s, int32_t* zero8 = nullptr);
 int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s);
 int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s);
 size_t match_ws_bytes(int64_t N);
@@ -206,7 +206,7 @@ int segment_sum2(const float* x, int C, const int32_t* segptr1, const int32_t* m
 int segment_max2_fwd(const float* x, int C, const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
                      const int32_t* members2, int64_t nseg2, float* out, int32_t* arg12, hipStream_t s);
 int segment_max2_bwd(const float* gout, const int32_t* arg12, const int32_t* seg12, int C, int64_t nseg2, int64_t n_fine,
-                     float* gx, hipStream_t s);
+                     float* gx, int add, hipStream_t s);
 int segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, int C, int64_t nseg, int64_t n_fine,
                     float* gx, hipStream_t s);
 int segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,

@@ -143,8 +143,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   void* ws_m = b.take<char>(mws);
   void* ws_p = b.take<char>(pws);
   if (!b.ok) return kArenaFull;
-  GEOBI_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), s));
-  GEOBI_TRY(edge_weight_t10(x, C, g.row, g.col, g.w, E, w10, s));
+  GEOBI_TRY(edge_weight_t10(x, C, g.row, g.col, g.w, E, w10, s, counters));      // also clears the 8 counters
   // inputs of step t: the level itself (t = 0) or step 0's coarse graph padded to P rows (t = 1)
   const int32_t* in_rp[2] = {g.rowptr, rowptr_c[0]};
   const int32_t* in_cl[2] = {g.col, col_c[0]};
@@ -336,18 +335,17 @@ int conv_bwd(Bump& b, const ConvSave& c, const geobi_conv_params_t& grad, const 
   return 0;
 }
 
-// pooling backward: gradient of the pooled features [R2, C] -> gradient of the layer input [P, C]
-int pool_bwd(Bump& b, const PoolSave& p, const float* g2, float** gx, hipStream_t s) {
-  float* g1 = p.pool_mean ? b.take<float>((size_t)p.R1 * p.C) : nullptr;
+// pooling backward: gradient of the pooled features [R2, C], ADDED to `acc` [P, C] (the gradient the layer input
+// already has from its skip connection)
+int pool_bwd(Bump& b, const PoolSave& p, const float* g2, float* acc, hipStream_t s) {
+  if (!p.pool_mean) return segment_max2_bwd(g2, p.arg[1], p.unpool, p.C, p.R2, p.P, acc, 1, s);
+  float* g1 = b.take<float>((size_t)p.R1 * p.C);
   float* g0 = b.take<float>((size_t)p.P * p.C);
   if (!b.ok) return kArenaFull;
-  if (p.pool_mean) {
-    GEOBI_TRY(segment_mean_bwd(g2, p.seg[1], p.segptr[1], p.C, p.R1, g1, s));
-    GEOBI_TRY(segment_mean_bwd(g1, p.seg[0], p.segptr[0], p.C, p.P, g0, s));
-  } else {
-    GEOBI_TRY(segment_max2_bwd(g2, p.arg[1], p.unpool, p.C, p.R2, p.P, g0, s));
-  }
-  *gx = g0;
+  GEOBI_TRY(segment_mean_bwd(g2, p.seg[1], p.segptr[1], p.C, p.R1, g1, s));
+  GEOBI_TRY(segment_mean_bwd(g1, p.seg[0], p.segptr[0], p.C, p.P, g0, s));
+  add_inplace_kernel<<<cdiv(p.P * p.C, 256), 256, 0, s>>>(acc, g0, p.P * p.C);
+  GEOBI_LAUNCH_OK();
   return 0;
 }
 
@@ -378,14 +376,9 @@ int gnn_backward(Bump& b, const BranchTape& t, const geobi_gnn_params_t& grad, c
                          N2, g_x2, s));
   GEOBI_TRY(conv_bwd(b, t.conv[3], grad.conv[3], g_x2, g_x2a, nullptr, accumulate, s));
   GEOBI_TRY(conv_bwd(b, t.conv[2], grad.conv[2], g_x2a, g_x2p, nullptr, accumulate, s));
-  float* g_pool = nullptr;
-  GEOBI_TRY(pool_bwd(b, t.pool[1], g_x2p, &g_pool, s));
-  add_inplace_kernel<<<cdiv(N1 * 64, 256), 256, 0, s>>>(g_x1, g_pool, N1 * 64);      // skip (r_conv2) + pooling2 paths
-  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(pool_bwd(b, t.pool[1], g_x2p, g_x1, s));                  // skip (r_conv2) + pooling2 paths
   GEOBI_TRY(conv_bwd(b, t.conv[1], grad.conv[1], g_x1, g_x1p, nullptr, accumulate, s));
-  GEOBI_TRY(pool_bwd(b, t.pool[0], g_x1p, &g_pool, s));
-  add_inplace_kernel<<<cdiv(N0 * 32, 256), 256, 0, s>>>(g_x0, g_pool, N0 * 32);      // skip (r_conv4) + pooling1 paths
-  GEOBI_LAUNCH_OK();
+  GEOBI_TRY(pool_bwd(b, t.pool[0], g_x1p, g_x0, s));                  // skip (r_conv4) + pooling1 paths
   GEOBI_TRY(conv_bwd(b, t.conv[0], grad.conv[0], g_x0, dx_in, nullptr, accumulate, s));
   return 0;
 }

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void edge_weight_t10_kernel(const float* __res
                                                               const int* __restrict__ row,
                                                               const int* __restrict__ col,
                                                               const float* __restrict__ w_in, int64_t E,
-                                                              float* __restrict__ w_out) {
+                                                              float* __restrict__ w_out, int* __restrict__ zero8) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero8 != nullptr && t < 8) zero8[t] = 0;     // the pooling layer's counters, cleared on the way (one fill launch less)
   int64_t e = t >> 3;
   int l = (int)(t & 7);
   bool ok = e < E;
@@ -477,7 +478,7 @@ __global__ void segment_max2_fwd_kernel(const float* __restrict__ x, int C, cons
 // gather form of its backward: fine row n receives the gradient of its composed segment where it was the arg-max
 __global__ void segment_max2_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ arg12,
                                         const int* __restrict__ seg12, int C, int64_t total, int nseg2,
-                                        float* __restrict__ gx) {
+                                        float* __restrict__ gx, int add) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int n = (int)(t / C), c = (int)(t % C);
@@ -487,7 +488,7 @@ __global__ void segment_max2_bwd_kernel(const float* __restrict__ gout, const in
     const size_t o = (size_t)sg * C + c;
     if (arg12[o] == n) v = gout[o];
   }
-  gx[t] = v;
+  gx[t] = add ? gx[t] + v : v;                  // add: on top of what gx holds (a skip connection's gradient)
 }
 
 // gather form: fine row n receives the gradient of its segment where it was the arg-max (every
@@ -1091,9 +1092,9 @@ int scan_exclusive_i32(void* temp, size_t temp_bytes, const int* in, int* out, i
 }
 
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
-                    float* w_out, hipStream_t s) {
+                    float* w_out, hipStream_t s, int32_t* zero8) {
   if (E <= 0) return 0;
-  edge_weight_t10_kernel<<<cdiv(E * 8, 256), 256, 0, s>>>(x, C, row, col, w_in, E, w_out);
+  edge_weight_t10_kernel<<<cdiv(E * 8, 256), 256, 0, s>>>(x, C, row, col, w_in, E, w_out, zero8);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -1325,9 +1326,9 @@ int segment_max2_fwd(const float* x, int C, const int32_t* segptr1, const int32_
 }
 
 int segment_max2_bwd(const float* gout, const int32_t* arg12, const int32_t* seg12, int C, int64_t nseg2, int64_t n_fine,
-                     float* gx, hipStream_t s) {
+                     float* gx, int add, hipStream_t s) {
   if (n_fine <= 0) return 0;
-  segment_max2_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, arg12, seg12, C, n_fine * C, (int)nseg2, gx);
+  segment_max2_bwd_kernel<<<cdiv(n_fine * C, 256), 256, 0, s>>>(gout, arg12, seg12, C, n_fine * C, (int)nseg2, gx, add);
   GEOBI_LAUNCH_OK();
   return 0;
 }
