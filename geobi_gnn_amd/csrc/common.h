@@ -219,7 +219,8 @@ size_t pool_edge_rows_ws_bytes_onepass(int64_t nbound, int64_t E);
 int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
                    const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
                    int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
-                   size_t ws_bytes, hipStream_t s, int64_t E_fine = 0, const void* rowinfo_in = nullptr);
+                   size_t ws_bytes, hipStream_t s, int64_t E_fine = 0, const void* rowinfo_in = nullptr,
+                   const int32_t* publish_src = nullptr, int32_t* publish_host = nullptr, int publish_seq = 0);
 size_t pool_edge_ws_bytes(int64_t E);
 int pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E, int64_t nmax,
               int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, void* ws,

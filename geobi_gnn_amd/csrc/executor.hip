@@ -158,18 +158,43 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     return match_coarsen(in_rp[t], in_cl[t], in_w[t], P, rounds[t], init, state[t], craw[t], cnew[t], segptr[t], members[t],
                          counters + 4 * t, ws_m, mws, s, rowinfo, &rowinfo_ok);
   };
-  auto run_edges = [&](int t) {
+  // The sizes come back through mapped host memory, written by the last kernel of the pipeline as soon as it starts
+  // (pool_edge_compact_kernel), not by a copy behind it.
+  static thread_local int32_t* pub = nullptr;
+  static thread_local int pub_seq = 0;
+  if (pub == nullptr) {
+    GEOBI_HIP(hipHostMalloc((void**)&pub, 16 * sizeof(int32_t), hipHostMallocMapped));
+    for (int i = 0; i < 16; ++i) pub[i] = 0;
+  }
+  auto run_edges = [&](int t, bool publish) {
     int32_t* ctr = counters + 4 * t;
     return pool_edge_rows(cnew[t], segptr[t], members[t], in_rp[t], in_cl[t], in_w[t], ctr + 1, P, rowptr_c[t], row_c[t],
                           col_c[t], w_c[t], ctr + 2, ctr + 3, ws_p, pws, s, E,      // E bounds both steps' edge counts
-                          rowinfo_ok ? rowinfo : nullptr);
+                          rowinfo_ok ? rowinfo : nullptr, publish ? counters : nullptr, publish ? pub : nullptr,
+                          pub_seq);
   };
+  pub_seq = pub_seq >= (1 << 30) ? 1 : pub_seq + 1;
   for (int t = 0; t < 2; ++t) {
     GEOBI_TRY(run_match(t, 1));
-    GEOBI_TRY(run_edges(t));
+    GEOBI_TRY(run_edges(t, t == 1));
   }
   int32_t h[8];
-  GEOBI_TRY(geobi_read_i32(counters, 8, h, (void*)s));
+  {
+    volatile int32_t* vp = pub;
+    long spins = 0;
+    bool got = false;
+    while (!(got = (__atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq))) {
+      if ((++spins & 0xfffff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {     // the stream ran dry without a word
+        got = __atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq;
+        break;
+      }
+    }
+    if (got) {
+      for (int i = 0; i < 8; ++i) h[i] = vp[i];
+    } else {
+      GEOBI_TRY(geobi_read_i32(counters, 8, h, (void*)s));
+    }
+  }
   // Rare repairs, each followed by a fresh read (the reference syncs after every step anyway): a matching whose
   // proposal chains outlast the rounds run so far is resumed from its saved state with twice the rounds; a coarse
   // row wider than the sort-free 64 entries sends that step through the radix-sort edge coarsening.  A repaired
@@ -181,7 +206,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
       rounds[t] *= 2;
       GEOBI_TRY(run_match(t, 0));
       GEOBI_HIP(hipMemsetAsync(counters + 4 * t + 2, 0, 2 * sizeof(int32_t), s));
-      GEOBI_TRY(run_edges(t));
+      GEOBI_TRY(run_edges(t, false));
     } else {                                          // sort-free width exceeded: general path for this step
       const int64_t Et = t == 0 ? E : (int64_t)h[2];
       const size_t gws = pool_edge_ws_bytes(Et);
@@ -197,7 +222,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
       rounds[1] = kRounds;
       GEOBI_HIP(hipMemsetAsync(counters + 4, 0, 4 * sizeof(int32_t), s));
       GEOBI_TRY(run_match(1, 1));
-      GEOBI_TRY(run_edges(1));
+      GEOBI_TRY(run_edges(1, false));
     }
     GEOBI_TRY(geobi_read_i32(counters, 8, h, (void*)s));
   }

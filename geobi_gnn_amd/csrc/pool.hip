@@ -728,9 +728,24 @@ __global__ __launch_bounds__(256) void pool_edge_compact_kernel(const int* __res
                                                                 const int4* __restrict__ rowinfo,
                                                                 const int* __restrict__ tcol, const float* __restrict__ tw,
                                                                 int* __restrict__ row_c, int* __restrict__ col_c,
-                                                                float* __restrict__ w_c, int* __restrict__ total) {
+                                                                float* __restrict__ w_c, int* __restrict__ total,
+                                                                const int* publish_src, int* publish_host, int publish_seq) {
   const int A = (blockIdx.x * 256 + threadIdx.x) >> 4, k = threadIdx.x & 15;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *total = rowptr_c[nbound];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int tot = rowptr_c[nbound];
+    *total = tot;
+    if (publish_host != nullptr) {
+      // The sizes the host is waiting for are all final once this kernel has started (its own total included):
+      // thread 0 hands them over through mapped host memory right away -- the host learns them while the copy pass
+      // below is still running, without a device-to-host copy launch and a stream drain in between.
+      for (int i = 0; i < 8; ++i) {
+        const int* src = publish_src + i;
+        publish_host[i] = (src == total) ? tot : *src;
+      }
+      __threadfence_system();
+      __hip_atomic_store(publish_host + 8, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (A >= nbound || A >= *ncount) return;
   const int o = rowptr_c[A], c = rowptr_c[A + 1] - o;
   const int4 ri = rowinfo[A];
@@ -1380,7 +1395,8 @@ size_t pool_edge_rows_ws_bytes(int64_t nbound) {
 int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* members, const int32_t* rowptr,
                    const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound, int32_t* rowptr_c,
                    int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count, int32_t* overflow, void* ws,
-                   size_t ws_bytes, hipStream_t s, int64_t E_fine, const void* rowinfo_in) {
+                   size_t ws_bytes, hipStream_t s, int64_t E_fine, const void* rowinfo_in, const int32_t* publish_src,
+                   int32_t* publish_host, int publish_seq) {
   GEOBI_REQUIRE(nbound > 0, "pool_edge_rows: empty");
   Arena a(ws, ws_bytes);
   int* cnt = a.take<int>(nbound + 1);
@@ -1401,7 +1417,8 @@ int pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32_t* me
     GEOBI_LAUNCH_OK();
     GEOBI_HIP(exclusive_scan_int(temp, tb, cnt, rowptr_c, nbound + 1, s));
     pool_edge_compact_kernel<<<cdiv(nbound * 16, 256), 256, 0, s>>>(ncount, (int)nbound, rowptr_c, rowinfo, tcol,
-                                                                    w ? tw : nullptr, row_c, col_c, w_c, count);
+                                                                    w ? tw : nullptr, row_c, col_c, w_c, count,
+                                                                    publish_src, publish_host, publish_seq);
     GEOBI_LAUNCH_OK();
     return 0;
   }
