@@ -138,6 +138,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     rowptr_c[t] = b.take<int32_t>(P + 1); row_c[t] = b.take<int32_t>(E); col_c[t] = b.take<int32_t>(E);
     w_c[t] = b.take<float>(E);
   }
+  int32_t* unpool = b.take<int32_t>(P);          // composed fine -> coarse index (its size does not wait for the counts)
   const size_t m = b.mark();
   const size_t mws = match_coarsen_ws_bytes(P), pws = pool_edge_rows_ws_bytes_onepass(P, E);
   void* ws_m = b.take<char>(mws);
@@ -178,6 +179,9 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     GEOBI_TRY(run_match(t, 1));
     GEOBI_TRY(run_edges(t, t == 1));
   }
+  // something for the device to do while the host reads the sizes and prepares the next launches
+  compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
+  GEOBI_LAUNCH_OK();
   int32_t h[8];
   {
     volatile int32_t* vp = pub;
@@ -199,7 +203,9 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   // proposal chains outlast the rounds run so far is resumed from its saved state with twice the rounds; a coarse
   // row wider than the sort-free 64 entries sends that step through the radix-sort edge coarsening.  A repaired
   // first step invalidates the second, which is then redone from scratch.
+  bool repaired = false;
   for (int repair = 0; repair < 12 && (h[0] || h[3] || h[4] || h[7]); ++repair) {
+    repaired = true;
     const int t = (h[0] || h[3]) ? 0 : 1;
     if (h[4 * t]) {                                   // undecided nodes: resume
       if (rounds[t] >= 2048) break;
@@ -226,6 +232,10 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     }
     GEOBI_TRY(geobi_read_i32(counters, 8, h, (void*)s));
   }
+  if (repaired) {                                   // the cluster vectors changed under the early composition
+    compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
+    GEOBI_LAUNCH_OK();
+  }
   b.release(m);
   if (h[0] || h[3] || h[4] || h[7]) return kFallback;         // not repaired within the budget
   const int64_t R1 = h[1], E1 = h[2];
@@ -233,7 +243,6 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   if (E1 <= 0 || E2 <= 0 || R1 <= 0 || R2 <= 0) return kFallback;
   // ---- features with exact sizes
   float* x2 = b.take<float>((size_t)R2 * C);
-  int32_t* unpool = b.take<int32_t>(P);
   int32_t *arg2 = nullptr, *pos_rev = nullptr;
   if (save) {       // training: arg-max rows and the coarse level's reverse-edge index stay
     arg2 = b.take<int32_t>((size_t)R2 * C);
@@ -251,8 +260,6 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     // segment_max passes (pool.hip), the step-one maxima are never written
     GEOBI_TRY(segment_max2_fwd(x, C, segptr[0], members[0], segptr[1], members[1], R2, x2, arg2, s));
   }
-  compose_index_kernel<<<cdiv(P, 256), 256, 0, s>>>(cnew[0], cnew[1], P, unpool);
-  GEOBI_LAUNCH_OK();
   if (save) {
     GEOBI_TRY(csr_reverse_index(rowptr_c[1], row_c[1], col_c[1], E2, pos_rev, nullptr, s));
     save->C = C; save->pool_mean = pool_mean; save->P = P; save->R1 = R1; save->R2 = R2;
