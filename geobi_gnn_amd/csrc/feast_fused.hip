@@ -495,8 +495,12 @@ __global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
 // or self loop), and the softmax backward runs once all four chunks are in.  The partial dot products of a node's
 // first 16 items wait in registers; nodes with more items park the rest in the rows they overwrite at the end anyway
 // (dl rows of the edges, the node's dcs row for the self loop).
+// Nine waves per workgroup: one dz tile (head) per wave in the matrix phase -- with eight, one wave had two tiles per
+// chunk and the other seven waited at the barrier.  The ninth wave takes no part in the row pass.  100 registers per
+// lane: five waves per SIMD, so two such workgroups still share a CU.
+constexpr int KT9 = 64 * H;
 template <int COUT>
-__global__ __launch_bounds__(512, 4) void feast_rowpass_fused128_kernel(
+__global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
     const float* __restrict__ gout, const float* __restrict__ out_act, float slope, const float* __restrict__ Wf,
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused128_kernel(
   // ---- g tile (as in the kernel above)
   {
     constexpr int Q = COUT / 4;
-    for (int i = threadIdx.x; i < TN * Q; i += 512) {
+    for (int i = threadIdx.x; i < TN * Q; i += KT9) {
       const int r = i / Q, c4 = (i - r * Q) * 4;
       const int gn = tile * TN + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -537,9 +541,9 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused128_kernel(
 
   // ---- row-pass roles: group of 16 lanes <-> node, lane k <-> one item per chunk of 16 items
   const int g = lane / G, k = lane % G;
-  const int nl = wave * NPW + g;
+  const int nl = (wave < NW ? wave : 0) * NPW + g;            // wave 8: matrix phase only
   const int node = tile * TN + nl;
-  const bool valid = node < N;
+  const bool valid = node < N && wave < NW;
   const int ns = valid ? node : N - 1;
   const int rs = rowptr[ns];
   const int deg = valid ? rowptr[ns + 1] - rs : -1;            // items = deg edges + the self loop; none if invalid
@@ -556,13 +560,12 @@ __global__ __launch_bounds__(512, 4) void feast_rowpass_fused128_kernel(
   static_assert(NKB % HB == 0, "whole weight batches");
   static_for<0, NCC>([&](auto cci) {
     constexpr int cc = decltype(cci)::value;
-    // ---- matrix phase: head h's 32 columns of this channel chunk = dz tile h; wave w takes tile w, wave 0 also tile 8
+    // ---- matrix phase: head h's 32 columns of this channel chunk = dz tile h = wave h's
     {
       const float* arow = s_g + l31 * GL + 4 * hf;
-#pragma unroll
-      for (int rnd = 0; rnd < 2; ++rnd) {
-        const int t = wave + 8 * rnd;
-        if (t < H) {                                           // wave-uniform
+      {
+        const int t = wave;                                    // nine waves, nine heads
+        {
           const float* brow = Wf + (size_t)(t * C + cc * CCH + l31) * COUT + 4 * hf;
           f32x16 acc;
 #pragma unroll
@@ -916,7 +919,7 @@ int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const floa
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_rowpass_fused128_kernel<COUT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+  feast_rowpass_fused128_kernel<COUT><<<xcd_grid(cdiv(N, TN)), KT9, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn, dcs, ld_dcs);
   GEOBI_LAUNCH_OK();
   return 0;
