@@ -303,11 +303,13 @@ def test_matching_equals_sorted_greedy(dev, n, m, ties):
     assert all((int(c[u]) * n + int(u)) in eset for u in paired[:200])
 
 
-def test_relabel_matches_consecutive_cluster(dev):
+# 5000: the one-block scan; 16384 / 16385: its boundary to the multi-block look-back scan; 70001: 18 look-back blocks
+# with a ragged tail; 262144 / 262145: the boundary to rocPRIM
+@pytest.mark.parametrize('n', [5000, 16384, 16385, 70001, 262144, 262145])
+def test_relabel_matches_consecutive_cluster(dev, n):
     from geobi_gnn_amd import net_util
     from oracle import pyg_ops as P
     g = torch.Generator().manual_seed(1)
-    n = 5000
     cluster = torch.randint(0, n, (n,), generator=g)
     cnew, count = net_util.relabel(cluster.to(torch.int32).to(dev))
     ref, _ = P.consecutive_cluster(cluster)
