@@ -167,6 +167,7 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
               int Cout, float slope, float* out, float* p, float* z, float* wf_out, void* ws, size_t ws_bytes,
               hipStream_t s, const float* bf_packed = nullptr);
 size_t feast_bwd_ws_bytes(int64_t N, int64_t E, int Cin, int Cout);
+size_t feast_bwd_ws_bytes_for(int64_t N, int64_t E, int Cin, int Cb, int Cout, bool need_dx);
 int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
               const int32_t* col_in, const int32_t* rowptr_out, const int32_t* col_out, const int32_t* pos_in,
               const float* lin_w, const float* u_w, const float* cvec, int Cout, float slope, const float* out,

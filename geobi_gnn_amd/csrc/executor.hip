@@ -355,7 +355,7 @@ int conv_bwd(Bump& b, const ConvSave& c, const geobi_conv_params_t& grad, const 
              int accumulate, hipStream_t s) {
   const Level& g = *c.g;
   const size_t m = b.mark();
-  const size_t wsb = feast_bwd_ws_bytes(g.N, g.E, c.Ca + c.Cb, c.Cout);
+  const size_t wsb = feast_bwd_ws_bytes_for(g.N, g.E, c.Ca + c.Cb, c.Cb, c.Cout, dxa != nullptr);
   void* ws = b.take<char>(wsb);
   if (!b.ok) return kArenaFull;
   GEOBI_TRY(feast_bwd(c.xa, c.xb, c.Ca, c.Cb, g.N, g.E, g.rowptr, g.col, g.rowptr, g.col, g.pos_rev, c.p->lin_w, c.p->u_w,
@@ -423,7 +423,8 @@ size_t branch_backward_bytes(const BranchTape& t) {
   size_t b = f(N0 * 32) * 2 + f(N0 * 64) + f(N1 * 64) * 3 + f(N1 * 128) + f(N2 * 128) * 2 + f(N2 * 64) + f(N1 * 32);
   for (int i = 0; i < 8; ++i) {
     const ConvSave& c = t.conv[i];
-    b += align_up(feast_bwd_ws_bytes(c.g->N, c.g->E, c.Ca + c.Cb, c.Cout));
+    // (the first layer may or may not owe an input gradient: without one its workspace is the larger)
+    b += align_up(feast_bwd_ws_bytes_for(c.g->N, c.g->E, c.Ca + c.Cb, c.Cb, c.Cout, i != 0));
   }
   for (int l = 0; l < 2; ++l) b += f(t.pool[l].R1 * t.pool[l].C) + f(t.pool[l].P * t.pool[l].C);
   return b;

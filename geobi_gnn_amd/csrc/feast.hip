@@ -793,16 +793,19 @@ struct BwdPlan {
   size_t tn_bytes, tn_bytes2, tn_bytes3, gemm_bytes;
 };
 
-static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dx, BwdPlan& b) {
+// need_dz: dz [N, 9 Cin] goes through HBM (no fused row pass for this shape);  need_z: z is recomputed here (fused
+// forward, no input gradient wanted).  The two [N, 9 Cin] arrays are most of a big layer's workspace (2 x 189 MB at
+// 82 k nodes and 64 channels): callers that know the path ask for what it needs (feast_bwd_ws_bytes_for).
+static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool need_dz, bool need_z, BwdPlan& b) {
   const int Kp = feast_ldz(Cin), ldr = feast_ldr(Cout);
   b.g = a.take<float>((size_t)N * Cout);
   b.wf = a.take<float>((size_t)Kp * Cout);
-  b.dz = a.take<float>((size_t)N * Kp);
+  b.dz = a.take<float>(need_dz ? (size_t)N * Kp : 4);
   b.dl = a.take<float>((size_t)(Ecap > 0 ? Ecap : 1) * HP);
   b.dpn = a.take<float>((size_t)N * HP);
   b.rp = a.take<float>((size_t)N * ldr);
   b.wp = a.take<float>((size_t)ldr * Cin);
-  b.z = a.take<float>((size_t)N * Kp);                       // fused forward, no dx wanted: z is recomputed here
+  b.z = a.take<float>(need_z ? (size_t)N * Kp : 4);          // fused forward, no dx wanted: z is recomputed here
   b.dpd = a.take<float>((size_t)N * 2 * HP);                 // fused: compact [dp | dcs]
   b.tn_bytes3 = 0;                                           // fused: x^T r' (per half for split inputs: fewer
   for (int rows : {Cin + 1, Cin, Cin / 2 + 1, Cin / 2}) {    // output tiles get more slabs)
@@ -821,17 +824,38 @@ static void plan_bwd(Arena& a, int64_t N, int64_t Ecap, int Cin, int Cout, bool 
     if ((Cin == 6 || Cin == 12) && du_bytes > b.tn_bytes2) b.tn_bytes2 = du_bytes;
   }
   b.tn_ws2 = a.take<char>(b.tn_bytes2);
-  size_t g1 = gemm_nn_ws_bytes(N, Kp), g2 = gemm_nn_ws_bytes(N, Cin);
+  size_t g1 = need_dz ? gemm_nn_ws_bytes(N, Kp) : 0, g2 = gemm_nn_ws_bytes(N, Cin);
   b.gemm_bytes = g1 > g2 ? g1 : g2;
   b.gemm_ws = a.take<char>(b.gemm_bytes);
-  (void)need_dx;
   b.total = align_up(a.off) + 256;
 }
 
+static bool rowpass_fused_enabled() {
+  static const bool on = [] { const char* f = getenv("GEOBI_ROWPASS_FUSED"); return !f || atoi(f) != 0; }();
+  return on;
+}
+
+// what feast_bwd will take from its workspace, from the same facts it decides its path with
+static void bwd_needs(int Cin, int Cb, int Cout, bool fused, bool need_dx, bool& need_dz, bool& need_z) {
+  need_dz = !(fused && rowpass_fused_enabled() && feast_rowpass_fused_supported(Cin, Cb, Cout));
+  need_z = fused && !need_dx;
+}
+
+// any path (the C ABI's query: the caller does not say which)
 size_t feast_bwd_ws_bytes(int64_t N, int64_t Ecap, int Cin, int Cout) {
   Arena a(nullptr, 0);
   BwdPlan b;
-  plan_bwd(a, N, Ecap, Cin, Cout, true, b);
+  plan_bwd(a, N, Ecap, Cin, Cout, true, true, b);
+  return b.total;
+}
+
+// the fused path with this input split and this need for an input gradient (the executor's query)
+size_t feast_bwd_ws_bytes_for(int64_t N, int64_t Ecap, int Cin, int Cb, int Cout, bool need_dx) {
+  bool need_dz, need_z;
+  bwd_needs(Cin, Cb, Cout, true, need_dx, need_dz, need_z);
+  Arena a(nullptr, 0);
+  BwdPlan b;
+  plan_bwd(a, N, Ecap, Cin, Cout, need_dz, need_z, b);
   return b.total;
 }
 
@@ -846,7 +870,9 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   GEOBI_REQUIRE(N > 0 && N < (1ll << 31), "feast_bwd: bad node count");
   Arena a(ws, ws_bytes);
   BwdPlan b;
-  plan_bwd(a, N, Ecap, Cin, Cout, dxa != nullptr, b);
+  bool need_dz, need_z;
+  bwd_needs(Cin, Cb, Cout, z == nullptr, dxa != nullptr, need_dz, need_z);
+  plan_bwd(a, N, Ecap, Cin, Cout, need_dz, need_z, b);
   GEOBI_REQUIRE(a.ok() && ws, "feast_bwd: workspace too small (%zu < %zu)", ws_bytes, b.total);
   const float* xb_ = xb ? xb : xa;
   const int Ca_ = Cb ? Ca : Cin;
@@ -866,8 +892,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
   }
   // One kernel for the first half of the backward when the layer reads <= 64 channels (GEOBI_ROWPASS_FUSED=0: A/B):
   // g, dz (LDS only), row pass.  Otherwise three: leaky-relu backward, dz GEMM (dz [N, 9 Cin] through HBM), row pass.
-  static const bool rp_fused_on = [] { const char* f = getenv("GEOBI_ROWPASS_FUSED"); return !f || atoi(f) != 0; }();
-  const bool rp_fused = fused && rp_fused_on && feast_rowpass_fused_supported(Cin, Cb, Cout);
+  const bool rp_fused = !need_dz;
   const float* g = gout;
   if (slope != 1.0f) g = b.g;
   if (rp_fused) {
