@@ -19,6 +19,13 @@ roofline  the forward fused FeaSt kernel (aggregation -- the "scatter-add" of th
           launch stream in a separate pass; `traffic` / `frac_by_counters` quote the committed PMC passes.
 cpu_baseline  the PyG-shaped CPU oracle (same op decomposition as the reference) on ONE mesh of
           the same size, all host cores, rank 0 at N = 1 only.
+extra     rank 0 at N = 1, after the timed region (never part of `value`):
+          infer        BASELINE configs[1] (one mesh n = 32) and configs[3] (one unsplit scan n = 87): network ms,
+                       M-edges/s and the fused kernel's algorithmic fraction of the HBM peak (test_dual.py:18-22,44-87)
+          fresh_batch  ms/step when every step unions 4 OTHER pre-processed meshes from a pool of 12 (what a loader
+                       hands over, train_dual.py:199-201) -- the per-union structures (reverse-edge index, corner
+                       lists, loss weights) are then rebuilt inside each step -- and the one-off per-mesh build
+N > 1     `config.collective_us` (the gradient all-reduce alone, HIP events), `config.rank_ms_per_step` (min / max).
 """
 import argparse
 import ctypes
@@ -142,6 +149,152 @@ def measure_mfma(net, bucket, opt, dv, df, steps=3):
     lib.geobi_prof_enable(0)
     lib.geobi_set_overlap(1)
     return out
+
+
+def delivered_edges(dv, df):
+    """Level-0 edge_index columns as the dataset delivers them (dataset.py:212-213,232: self loops appended to the
+    vertex graph, inline in the facet graph) for a pair whose adjacency is the loop-free CSR of the device
+    preprocessing: one loop per node on top of the stored edges."""
+    return dv.graph().E + dv.x.shape[0] + df.graph().E + df.x.shape[0]
+
+
+def fused_kernel_stats(lib, run, reps=3):
+    """HIP-event time and algorithmic bytes of the forward fused FeaSt launches of `run()`, dominant instantiation."""
+    from geobi_gnn_amd import _lib as L
+    lib.geobi_prof_enable(1)
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    best = None
+    for cin in (6, 12, 32, 64, 128):
+        for cout in (32, 64, 128):
+            n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+            L.check(lib.geobi_prof_collect(cin * 1000 + cout, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)),
+                    'prof_collect')
+            if n.value and (best is None or ms.value > best[1]):
+                best = ('%d->%d' % (cin, cout), ms.value, by.value, n.value)
+    lib.geobi_prof_enable(0)
+    gbs = best[2] / (best[1] * 1e-3) / 1e9
+    return {'layer': 'FeaStConv ' + best[0], 'launches': best[3], 'avg_us': round(best[1] * 1e3 / best[3], 2),
+            'achieved': round(gbs, 1), 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def measure_infer(net, device):
+    """BASELINE configs[1] / configs[3]: single-mesh inference (test_dual.py:18-22: forward under no_grad) of one
+    noisy icosphere n = 32 (F = 20 480) and one unsplit scan-sized n = 87 (F = 151 380), inputs resident in HBM.
+    Same weights as the training net (random init + the timed steps).  The meshes come from the device
+    preprocessing (meshprep.build_dual_data: same fields as the host generator, loop-free CSR)."""
+    from geobi_gnn_amd import meshgen, meshprep, infer, _lib as L
+    lib = L.lib()
+    out = {}
+    for key, name, n, reps in (('configs[1]', 'Synthetic test_list single-mesh inference', 32, 30),
+                               ('configs[3]', 'Kinect_Fusion-sized large scan, unsplit', 87, 15)):
+        noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed=7)
+        dv, df = meshprep.build_dual_data(noisy, faces, clean, device=device)
+        edges = delivered_edges(dv, df)
+        vf = dv.meta['vf_indices']
+        run = lambda: infer.predict_one_submesh(net, (dv, df))
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize(); t_net = (time.perf_counter() - t0) / reps
+        full = lambda: infer.predict_one(net, dv, df, dv.meta['centroid'], dv.meta['scale'], vf, 60)
+        full()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(max(3, reps // 3)):
+            full()
+        torch.cuda.synchronize(); t_all = (time.perf_counter() - t0) / max(3, reps // 3)
+        out[key] = {'workload': '%s: icosphere n=%d (F=%d, %d level-0 edges)' % (name, n, df.x.shape[0], edges),
+                    'network_ms': round(t_net * 1e3, 3), 'M_edges_per_s': round(edges / t_net / 1e6, 1),
+                    'with_60_sweep_vertex_update_ms': round(t_all * 1e3, 3),
+                    'fused_feast_kernel': fused_kernel_stats(lib, run)}
+        log('infer %s: %.3f ms network, %.1f M-edges/s' % (key, t_net * 1e3, edges / t_net / 1e6))
+    return out
+
+
+def measure_fresh_batch(net, bucket, opt, device, freq, pool_size=12, steps=12, warm=3):
+    """The same training step when every step sees 4 OTHER meshes (train_dual.py:199-201: the loader hands a new
+    mesh each iteration): a pool of pre-processed meshes resident in HBM (device preprocessing, timed as the one-off
+    per-mesh structure build), each step unions 4 of them (data.union_batch_graphs: CSR concatenation, no sort) and
+    rebuilds what the replayed bench batch caches -- reverse-edge index, vertex -> corner lists, loss weights."""
+    from geobi_gnn_amd import meshgen, meshprep
+    from geobi_gnn_amd.data import union_batch_graphs
+    raw = [meshgen.noisy_icosphere(freq, (0.1, 0.2, 0.3)[i % 3], seed=500 + i) for i in range(pool_size)]
+    meshprep.build_dual_data(raw[0][0], raw[0][2], raw[0][1], device=device)          # warm the kernels' first launch
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pool = [meshprep.build_dual_data(noisy, faces, clean, device=device) for noisy, clean, faces in raw]
+    torch.cuda.synchronize(); build_ms = (time.perf_counter() - t0) * 1e3 / pool_size
+    edges = [delivered_edges(dv, df) for dv, df in pool]
+
+    def step(k):
+        idx = [(k + 3 * i) % pool_size for i in range(BATCH)]        # 12 different unions for k = 0 .. 11
+        dv, df = union_batch_graphs([pool[i] for i in idx])
+        train_step(net, bucket, opt, dv, df, collective=False)
+        return sum(edges[i] for i in idx)
+    for k in range(warm):
+        step(k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    total = 0
+    for k in range(steps):
+        total += step(warm + k)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    log('fresh batch: %.3f ms/step, per-mesh structure build %.3f ms' % (dt / steps * 1e3, build_ms))
+    return {'workload': 'every step unions %d other meshes (n=%d) from a pool of %d pre-processed meshes resident in '
+                        'HBM; union + per-union structures (reverse-edge index, corner lists, loss weights) inside '
+                        'the step' % (BATCH, freq, pool_size),
+            'ms_per_step': round(dt / steps * 1e3, 3), 'M_edges_per_s': round(total / dt / 1e6, 2), 'steps': steps,
+            'structure_build_ms_per_mesh': round(build_ms, 3),
+            'structure_build': 'device preprocessing of one raw mesh (points + faces -> both level-0 CSR graphs, '
+                               'normals, bilateral weights, features; meshprep.build_dual_data), one-off per mesh'}
+
+
+def measure_collective(bucket, before=None, after=None, steps=5):
+    """N > 1: the gradient all-reduce alone, in steps of their own after the timed region: `before()` refills the
+    bucket (forward + backward), then bucket.all_reduce_mean() is bracketed by HIP events on the compute stream
+    (wall clock for CPU tensors: the gloo plumbing test).  Median over `steps`, microseconds."""
+    us = []
+    cuda = bucket.flat.is_cuda
+    for _ in range(steps):
+        if before is not None:
+            before()
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()
+            e1.record()
+        else:
+            t0 = time.perf_counter()
+            bucket.all_reduce_mean()
+            t1 = time.perf_counter()
+        if after is not None:
+            after()
+        if cuda:
+            torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3)
+        else:
+            us.append((t1 - t0) * 1e6)
+    us.sort()
+    return us[len(us) // 2]
+
+
+def multi_rank_fields(my_ms, coll_us, device):
+    """What a scaling line needs to explain itself (config.* at N > 1): backend, every rank's own step time (min /
+    max over ranks) and the all-reduce alone (max over ranks)."""
+    import torch.distributed as dist
+    r = torch.tensor([my_ms], dtype=torch.float64, device=device)
+    lo, hi = r.clone(), r.clone()
+    c = torch.tensor([coll_us], dtype=torch.float64, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c, op=dist.ReduceOp.MAX)
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+            'collective_us': round(float(c.item()), 1),
+            'collective_note': 'median of 5 all-reduces of the flat gradient bucket incl. the division by the world '
+                               'size (HIP events on the compute stream), max over ranks; separate steps after the '
+                               'timed region',
+            'rank_ms_per_step': {'min': round(float(lo.item()), 3), 'max': round(float(hi.item()), 3)}}
 
 
 def host_cores():
@@ -271,6 +424,7 @@ def main():
     ap.add_argument('--freq', type=int, default=FREQ, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip extra.infer / extra.fresh_batch')
     ap.add_argument('--plumbing', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -286,12 +440,22 @@ def main():
         # launcher / rendezvous / collective plumbing only (tests/test_host_logic.py drives the N > 1 branch on a
         # box without a GPU): no workload runs and no number is reported
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        cfg = {}
         if world > 1:
+            from geobi_gnn_amd.parallel import GradBucket
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            # the N > 1 fields of the real line, through the same helpers, on a bucket of the real size (host memory)
+            pb = GradBucket([torch.nn.Parameter(torch.zeros(939128))])
+            pb.flat.fill_(float(rank + 1))
+            t0 = time.perf_counter()
+            us = measure_collective(pb, steps=3)
+            cfg = multi_rank_fields((time.perf_counter() - t0) * 1e3 / 3, us, torch.device('cpu'))
+            cfg['bucket_mean'] = float(pb.flat[0])
             dist.barrier()
         if rank == 0:
             print(json.dumps({'metric': 'M-edges/s (fwd+bwd) on Synthetic set', 'value': None, 'n_gpus': world,
-                              'plumbing': True, 'rank_sum': t.item(), 'backend': dist.get_backend() if world > 1 else None}),
+                              'plumbing': True, 'rank_sum': t.item(), 'backend': dist.get_backend() if world > 1 else None,
+                              'config': cfg}),
                   flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -300,9 +464,13 @@ def main():
         raise SystemExit('bench.py: WORLD_SIZE=%d but --gpus %d (launch through torch.distributed.run '
                          '--nproc-per-node %d, or from a bare shell)' % (world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no CPU fallback exists'
-    if world > 1:
-        assert dist.get_world_size() == args.gpus
     rehearsal = os.environ.get('GEOBI_ALL_RANKS_ON_DEVICE0') == '1' and world > 1
+    if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # a scaling line must come from RCCL with one device per rank; gloo / shared device only as a labelled rehearsal
+        assert rehearsal or (dist.get_backend() == 'nccl' and torch.cuda.device_count() >= world), \
+            'N > 1 outside a rehearsal needs backend nccl (RCCL) and %d devices: backend %s, %d visible' % (
+                world, dist.get_backend(), torch.cuda.device_count())
     _lib.lib()
 
     torch.manual_seed(0)                                  # random-init weights of the real architecture
@@ -334,7 +502,19 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    my_ms = elapsed / args.steps * 1e3
     elapsed, total_edges = float(t.item()), float(e.item())
+    mr = None
+    if world > 1:
+        # the line must explain a scaling loss by itself: every rank's own step time and the all-reduce alone
+        def refill():
+            from geobi_gnn_amd.parallel import batched_losses
+            bucket.zero()
+            a, b = dv.shallow_copy(), df.shallow_copy()
+            vp, npred, _ = net((a, b))
+            lv, ln = batched_losses(vp, npred, dv, df, 'L1', 'L1')
+            network.dual_loss(lv, ln).backward()
+        mr = multi_rank_fields(my_ms, measure_collective(bucket, refill, opt.step), device)
     if rank == 0:
         log('timed %d steps: %.3f ms/step' % (args.steps, elapsed / args.steps * 1e3))
 
@@ -347,12 +527,16 @@ def main():
         'config': {'workload': 'Synthetic train, batch=4 meshes (~20k faces each), fwd+bwd '
                                '[BASELINE.json configs[2]]: per rank 4 noisy icospheres n=%d (F=%d) as one '
                                'disjoint-union graph, L1/L1 loss, grad all-reduce + Adam step inside the timed '
-                               'region' % (args.freq, 20 * args.freq ** 2),
+                               'region; ONE resident batch replayed every step, its level-0 CSR / reverse-edge index / '
+                               'corner lists / loss weights built in warm-up and cached per mesh (extra.fresh_batch: '
+                               'other meshes every step)' % (args.freq, 20 * args.freq ** 2),
                    'meshes_per_rank': BATCH, 'edges_per_rank_step': edges, 'parallelism': 'dp%d' % world,
                    'collective': ('none' if world == 1 else
                                   '%s all-reduce of the flat fp32 gradient bucket' % dist.get_backend()),
                    'final_loss': round(float(loss.item()), 6)},
     }
+    if world > 1:
+        out['config'].update(mr)
     if rehearsal:
         out['config']['rehearsal'] = ('%d ranks share device 0 over gloo (fewer devices than ranks): checks the '
                                       'multi-rank path, NOT a scaling measurement' % world)
@@ -360,6 +544,9 @@ def main():
         if not args.no_roofline:
             out['roofline'] = measure_roofline(net, bucket, opt, dv, df)
             out['roofline_mfma'] = measure_mfma(net, bucket, opt, dv, df)
+        if world == 1 and not args.no_extra:
+            out['extra'] = {'infer': measure_infer(net, device),
+                            'fresh_batch': measure_fresh_batch(net, bucket, opt, device, args.freq)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.freq)
     if world > 1:

@@ -8,9 +8,15 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
 OBJS=()
 mkdir -p "$HERE/build"
+# every header is a dependency of every object (feast_dev.h is shared by feast.hip and feast_fused.hip; a stale
+# object would ship in the in-tree .so), and so is this script (compiler flags)
+HDRS=("$HERE"/*.h "$HERE/../../include"/*.h "$HERE/build.sh")
 for f in capi executor graph gemm feast feast_fused pool geom head_fused meshprep patch; do
   src="$HERE/$f.hip"; obj="$HERE/build/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/geobi_hip.h" -nt "$obj" ]; then
+  stale=0
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ]; then stale=1; fi
+  for h in "${HDRS[@]}"; do if [ "$h" -nt "$obj" ]; then stale=1; fi; done
+  if [ $stale = 1 ]; then
     echo "hipcc $f.hip"
     "$HIPCC" $FLAGS -c "$src" -o "$obj" &
   fi

@@ -118,6 +118,24 @@ def supported(net):
     return net.gnn_v.pooling1.pool_type == net.gnn_f.pooling1.pool_type
 
 
+def _check_inputs(net, data_v, data_f, fv32, dd, tensors):
+    """The library reads V / F rows through raw pointers: a malformed bag must raise here, not fault on the device
+    (the module path reports the same mismatches through FeastConvFn / FaceGeomFn)."""
+    V, F = data_v.x.shape[0], data_f.x.shape[0]
+    dev = data_v.x.device
+    if tuple(fv32.shape) != (F, 3):
+        raise L.GeobiError('fv_indices has shape %s; the facet graph has %d nodes: expected (%d, 3)'
+                           % (tuple(fv32.shape), F, F))
+    if data_f.x.device != dev or fv32.device != dev:
+        raise L.GeobiError('data_v and data_f live on different devices (%s, %s)' % (dev, data_f.x.device))
+    if net.force_depth:
+        if dd is None or dd.dim() != 2 or dd.shape[0] != V or dd.shape[1] != 3 or dd.device != dev:
+            raise L.GeobiError('force_depth: depth_direction must be a [%d, 3] tensor on %s' % (V, dev))
+    for t in tensors:
+        if t.device != dev:
+            raise L.GeobiError('parameters live on %s, the data on %s' % (t.device, dev))
+
+
 def _level0(data, keep):
     g = data.graph(data.x.shape[0])
     if not g.symmetric or g.E == 0:
@@ -170,8 +188,11 @@ def forward(net, data_v, data_f):
     fv32, _ = _fv_index(data_f, x_v.shape[0])
     dd = None
     if net.force_depth:
+        if getattr(data_v, 'depth_direction', None) is None:
+            raise L.GeobiError('force_depth: data_v.depth_direction is missing')
         dd = _f32(data_v.depth_direction, 'depth_direction')
     prm, pkeep = _pack_params(net)
+    _check_inputs(net, data_v, data_f, fv32, dd, pkeep)
     lib = L.lib()
     nbytes = L.size_query('geobi_net_forward_arena_bytes', lv_v.N, lv_v.E, lv_f.N, lv_f.E)
     out = _Out()
@@ -193,15 +214,41 @@ def forward(net, data_v, data_f):
     V, F = lv_v.N, lv_f.N
     verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
     normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
-    _set_module_state(net, arena, out)
+    # the forward's side effect on its input (network.py:337: data_f.x = cat(x_f, centroid, normal)), as the module
+    # path leaves it; copied out because the arena is reused by the next pass
+    data_f.x = _views(arena, out.xf_off, F * 12, torch.float32).view(F, 12).clone()
+    key = (dev.type, dev.index)
+    _GENERATION[key] = _GENERATION.get(key, 0) + 1
+    _set_module_state(net, arena, out, (key, _GENERATION[key]))
     return verts, normals
 
 
-def _set_module_state(net, arena, out):
-    """What the pooling modules expose after a forward (net_util.py:156): composed unpool index, raw cluster vectors."""
+# Inference passes share one arena per device, so what the pooling modules expose after a forward (views into it) is
+# overwritten by the NEXT pass of any net on that device.  Copying a dozen small vectors out per pass would cost ~40 us
+# of launches on a 1 ms pass; instead every pass bumps the device's generation and the modules refuse a stale read
+# (PoolingLayer._fresh) -- read them before the next forward, or run with GEOBI_NET_EXECUTOR=0.
+_GENERATION = {}
+
+
+def is_current(guard):
+    return guard is None or _GENERATION.get(guard[0]) == guard[1]
+
+
+def _clear_module_state(net):
+    """Drop the previous pass' views BEFORE the next arena is allocated (they would pin the old block)."""
+    for mod in (net.gnn_v, net.gnn_f):
+        for pl in (mod.pooling1, mod.pooling2):
+            pl._unpool32 = pl._unpool64 = pl._unpool_index = pl._last_clusters32 = None
+            pl._arena_guard = None
+
+
+def _set_module_state(net, arena, out, guard=None):
+    """What the pooling modules expose after a forward (net_util.py:156): composed unpool index, raw cluster vectors.
+    guard: (device key, generation) for views into the shared inference arena, None for a training pass' own arena."""
     for gname, bo in (('gnn_v', out.v), ('gnn_f', out.f)):
         mod = getattr(net, gname)
         for l, pl in enumerate((mod.pooling1, mod.pooling2)):
+            pl._arena_guard = guard
             pl._unpool32 = _views(arena, bo.unpool_off[l], bo.nodes[l], torch.int32)
             pl._unpool64 = None
             pl._unpool_index = None                  # the executor keeps its own inverse lists
@@ -246,10 +293,16 @@ def forward_train(net, data_v, data_f):
     dev = data_v.x.device
     x_v, x_f = _f32(data_v.x, 'data_v.x'), _f32(data_f.x, 'data_f.x')
     fv32, corner = _fv_index(data_f, x_v.shape[0])
-    dd = _f32(data_v.depth_direction, 'depth_direction') if net.force_depth else None
+    dd = None
+    if net.force_depth:
+        if getattr(data_v, 'depth_direction', None) is None:
+            raise L.GeobiError('force_depth: data_v.depth_direction is missing')
+        dd = _f32(data_v.depth_direction, 'depth_direction')
     tensors = [_f32(p.detach(), 'parameter') for p in params]
+    _check_inputs(net, data_v, data_f, fv32, dd, tensors)
     prm = _pack_pointers(tensors, net)
     keep += [tensors, x_v, x_f, fv32, dd, gv, gf]
+    _clear_module_state(net)
     lib = L.lib()
     shape_key = (lv_v.N, lv_v.E, lv_f.N, lv_f.E)
     nbytes = _LEARNED.get(shape_key) or L.size_query('geobi_net_train_arena_bytes', *shape_key)
@@ -276,8 +329,13 @@ def forward_train(net, data_v, data_f):
     _LEARNED[shape_key] = int(1.05 * int(out.used_bytes)) + (16 << 20)
     STATS['train_arena_bytes'], STATS['train_need_bytes'] = nbytes, int(out.used_bytes)
     V, F = lv_v.N, lv_f.N
-    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3)
-    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3)
+    # results are COPIED out (three small tensors): a view would pin the whole training arena (GBs) for as long as the
+    # caller keeps the prediction, and the next step's arena could not reuse the block
+    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
+    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
+    data_f.x = _views(arena, out.xf_off, F * 12, torch.float32).view(F, 12).clone()        # network.py:337
+    # the pooling modules' state stays a set of views into this pass' own arena (valid, but the block is held until
+    # the next training forward drops them -- before it allocates, see _clear_module_state -- so never two arenas)
     _set_module_state(net, arena, out)
     return verts, normals, Recorded(handle.value, arena, keep, net, corner)
 

@@ -36,8 +36,21 @@ def _icosahedron():
     return v, f
 
 
+_ICOSPHERES = {}
+
+
 def icosphere(n):
     """Class-I geodesic sphere of frequency ``n``: returns (points [V,3] f64, faces [F,3] i64)."""
+    if n not in _ICOSPHERES:
+        pts, faces = _icosphere(n)
+        pts.setflags(write=False)
+        faces.setflags(write=False)
+        _ICOSPHERES[n] = (pts, faces)           # the lattice walk below is a Python loop over 20 n^2 faces
+    pts, faces = _ICOSPHERES[n]
+    return pts.copy(), faces.copy()
+
+
+def _icosphere(n):
     assert n >= 1
     v0, f0 = _icosahedron()
     # barycentric lattice on every base triangle; vertices are identified through an

@@ -290,23 +290,36 @@ class PoolingLayer(nn.Module):
         self.graclus_fn = None          # optional: callable(edge_index, weight, num_nodes) -> cluster
         self._last_clusters32 = None    # raw cluster vectors of the last forward
         self._unpool_index = None
+        self._arena_guard = None        # set by the whole-network executor: state lives in a shared arena
+
+    def _fresh(self):
+        """After an inference pass through the whole-network executor the state below is a set of views into the
+        device's shared arena: the next pass overwrites it, and a read after that must fail, not return another
+        pass' numbers."""
+        from . import executor
+        if not executor.is_current(self._arena_guard):
+            raise L.GeobiError('PoolingLayer state (unpooling_indices / last_clusters) of an earlier inference pass '
+                               'was overwritten by a later forward on this device: read it before the next pass')
 
     @property
     def unpooling_indices(self):
         """Composed fine -> coarse index of the last forward (net_util.py:152-156), int64 like the reference
         keeps it; converted from the int32 the kernels use on first read."""
+        self._fresh()
         if self._unpool64 is None and self._unpool32 is not None:
             self._unpool64 = self._unpool32.long()
         return self._unpool64
 
     @unpooling_indices.setter
     def unpooling_indices(self, value):
+        self._arena_guard = None
         self._unpool64 = value
         self._unpool32 = None if value is None else value.to(torch.int32)
 
     @property
     def last_clusters(self):
         """Raw (pre-relabel) cluster vectors of the last forward, int64 like graclus returns them."""
+        self._fresh()
         return None if self._last_clusters32 is None else [c.long() for c in self._last_clusters32]
 
     # -- edge weight fed to the matching (no gradient is needed: it only drives integer matching)
@@ -390,6 +403,7 @@ class PoolingLayer(nn.Module):
                     break
 
         clust = _compose(clusts)
+        self._arena_guard = None
         self._unpool32, self._unpool64 = clust, None
         uidx = sidxs[0]
         for nxt in sidxs[1:]:
@@ -403,6 +417,7 @@ class PoolingLayer(nn.Module):
     def unpooling(self, x):
         if self._unpool32 is None:
             return x
+        self._fresh()
         if self._unpool_index is None:       # forward ran through the whole-network executor: lists built on demand
             nseg = int(self._unpool32.max().item()) + 1
             self._unpool_index = ops.SegmentIndex(self._unpool32.contiguous(), nseg)

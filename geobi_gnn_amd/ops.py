@@ -145,6 +145,14 @@ def _direct_grad(p):
     if p.grad is None or not p.grad.is_contiguous() or getattr(p, '_geobi_grad_ptr', None) != p.grad.data_ptr():
         raise L.GeobiError('a direct-gradient parameter lost its bucket view (optimizer.zero_grad(set_to_none=True) or '
                            'an assignment to .grad): zero the gradients with GradBucket.zero() instead')
+    bucket = getattr(p, '_geobi_bucket', None)
+    owner = None if bucket is None else bucket.owner
+    if owner is not None and (owner.grad is None or owner.grad.data_ptr() != bucket.flat.data_ptr()):
+        # FlatParameters: the optimizer steps ONE flat parameter.  zero_grad(set_to_none=True) on it leaves the
+        # per-parameter views intact, the kernels would keep adding into the bucket and optimizer.step() would skip
+        # the parameter without a word
+        raise L.GeobiError('the flat parameter lost its gradient bucket (optimizer.zero_grad(set_to_none=True) or an '
+                           'assignment to .grad): zero the gradients with GradBucket.zero() instead')
     return p.grad
 
 

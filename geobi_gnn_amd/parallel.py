@@ -104,6 +104,7 @@ class GradBucket(object):
             p.grad = v
             p._geobi_direct_grad = bool(direct)
             p._geobi_grad_ptr = v.data_ptr()
+            p._geobi_bucket = self           # ops._direct_grad also checks the flat owner's .grad (FlatParameters)
             off += n
 
     def zero(self):

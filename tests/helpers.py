@@ -50,3 +50,11 @@ def install_replay(net, clusters):
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]

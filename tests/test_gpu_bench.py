@@ -34,6 +34,18 @@ def test_bench_line_single_gpu():
     roof = out['roofline']
     assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert 'cached per mesh' in out['config']['workload']
+    # the inference configs and the fresh-batch figure ride in the same line
+    inf = out['extra']['infer']
+    for key, faces in (('configs[1]', 20480), ('configs[3]', 151380)):
+        e = inf[key]
+        assert 'F=%d' % faces in e['workload'] and e['network_ms'] > 0 and e['M_edges_per_s'] > 0
+        k = e['fused_feast_kernel']
+        assert k['unit'] == 'GB/s' and abs(k['frac'] - k['achieved'] / 8000.0) < 1e-3
+    fb = out['extra']['fresh_batch']
+    assert fb['ms_per_step'] > 0 and fb['structure_build_ms_per_mesh'] > 0
+    # 4 fresh meshes of the bench size per step: the same edge count as the replayed batch
+    assert abs(fb['M_edges_per_s'] * fb['ms_per_step'] - out['config']['edges_per_rank_step'] / 1e3) < 1e-2 * out['config']['edges_per_rank_step'] / 1e3
 
 
 def test_bench_two_ranks_from_a_bare_shell():
@@ -41,7 +53,11 @@ def test_bench_two_ranks_from_a_bare_shell():
     out = _bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--no-roofline', '--no-cpu-baseline')
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2'
     assert out['config']['edges_per_rank_step'] == 1351448
+    cfg = out['config']
     if torch.cuda.device_count() < 2:
-        assert 'rehearsal' in out['config'] and 'gloo' in out['config']['collective']
+        assert 'rehearsal' in cfg and 'gloo' in cfg['collective'] and cfg['backend'] == 'gloo'
     else:
-        assert 'rehearsal' not in out['config'] and 'nccl' in out['config']['collective']
+        assert 'rehearsal' not in cfg and 'nccl' in cfg['collective'] and cfg['backend'] == 'nccl'
+    assert cfg['world_size'] == 2 and cfg['collective_us'] > 0
+    assert 0 < cfg['rank_ms_per_step']['min'] <= cfg['rank_ms_per_step']['max']
+    assert cfg['rank_ms_per_step']['max'] <= out['ms_per_step'] * 1.001

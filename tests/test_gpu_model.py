@@ -412,6 +412,15 @@ def test_direct_gradients_accumulate_like_autograd(dev):
     assert flat.flat_param.grad is flat.bucket.flat
     backward(0)
     assert torch.equal(flat.bucket.flat, g0)
+    # the reference loop's optimizer.zero_grad() touches only the ONE flat parameter -- the per-parameter
+    # views stay attached, so without the owner check the kernels would add into a bucket the optimizer skips
+    opt.zero_grad()
+    assert flat.flat_param.grad is None and all(p.grad is not None for p in net.parameters())
+    with pytest.raises(GeobiError, match='flat parameter lost its gradient bucket'):
+        backward(0)
+    flat.bucket.zero()
+    backward(1)
+    assert torch.equal(flat.bucket.flat, g1)
 
 
 def test_losses_and_metrics_match_reference_fixture(dev):
@@ -563,6 +572,92 @@ def test_bad_face_table_is_rejected(dev):
     with pytest.raises(GeobiError, match='fv_indices'):
         with torch.no_grad():
             net((dv, df))
+
+
+def test_malformed_bags_raise_instead_of_reaching_the_device(dev):
+    """the executor hands raw pointers to the library -- a face table with the wrong row count, a
+    depth_direction of the wrong length or parameters on another device must raise GeobiError on the host (training
+    and inference), as the module path does, not become an out-of-bounds device read."""
+    from geobi_gnn_amd import network, meshgen, executor
+    from geobi_gnn_amd._lib import GeobiError
+    assert executor.ENABLED
+    dv0, df0 = meshgen.synthetic_dual_data(3, 0.2, seed=1)
+    dv0, df0 = dv0.to(dev), df0.to(dev)
+    net = network.DualGNN().to(dev)
+
+    def run(dv, df, net, train):
+        if train:
+            return net((dv, df))
+        with torch.no_grad():
+            return net((dv, df))
+    for train in (False, True):
+        dv, df = dv0.shallow_copy(), df0.shallow_copy()
+        df.fv_indices = df0.fv_indices[:-7].clone()                       # F - 7 rows for F facet nodes
+        with pytest.raises(GeobiError, match='fv_indices has shape'):
+            run(dv, df, net, train)
+        netd = network.DualGNN(force_depth=True).to(dev)
+        dv, df = dv0.shallow_copy(), df0.shallow_copy()
+        dv.depth_direction = torch.nn.functional.normalize(dv0.x[:-5, :3], dim=1)   # V - 5 rows
+        with pytest.raises(GeobiError, match='depth_direction'):
+            run(dv, df, netd, train)
+        dv, df = dv0.shallow_copy(), df0.shallow_copy()
+        dv.depth_direction = None
+        with pytest.raises(GeobiError, match='depth_direction'):
+            run(dv, df, netd, train)
+        cpu_net = network.DualGNN()                                        # parameters left on the host
+        with pytest.raises(GeobiError):
+            run(dv0.shallow_copy(), df0.shallow_copy(), cpu_net, train)
+    # and the well-formed bag still runs after all that
+    vp, npred, _ = run(dv0.shallow_copy(), df0.shallow_copy(), net, False)
+    assert bool(torch.isfinite(vp).all()) and bool(torch.isfinite(npred).all())
+
+
+def test_executor_side_effects_match_the_module_path(dev):
+    """(1) the reference's forward leaves data_f.x = cat(x_f, centroid, normal) (network.py:337): the
+    executor does too, with the same numbers as the module path; (2) predictions are copies, not views that pin the
+    arena; (3) pooling state of an inference pass is refused once a later pass has overwritten the shared arena."""
+    from geobi_gnn_amd import network, meshgen, executor
+    from geobi_gnn_amd._lib import GeobiError
+    dv0, df0 = meshgen.synthetic_dual_data(5, 0.2, seed=2)
+    dv0, df0 = dv0.to(dev), df0.to(dev)
+    torch.manual_seed(1)
+    net = network.DualGNN().to(dev)
+    was = executor.ENABLED
+    got = {}
+    try:
+        for on in (False, True):
+            executor.ENABLED = on
+            for train in (False, True):
+                dv, df = dv0.shallow_copy(), df0.shallow_copy()
+                if train:
+                    vp, npred, _ = net((dv, df))
+                else:
+                    with torch.no_grad():
+                        vp, npred, _ = net((dv, df))
+                assert df.x.shape == (df0.x.shape[0], 12)
+                got[(on, train)] = (df.x.clone(), vp.detach().clone(), npred.detach().clone())
+                if on:
+                    # copies: a prediction owns V * 3 / F * 3 floats, not the arena
+                    assert vp.untyped_storage().nbytes() == vp.numel() * 4
+                    assert npred.untyped_storage().nbytes() == npred.numel() * 4
+                    assert df.x.untyped_storage().nbytes() == df.x.numel() * 4
+        executor.ENABLED = True
+        with torch.no_grad():
+            net((dv0.shallow_copy(), df0.shallow_copy()))
+        first = net.gnn_v.pooling1.unpooling_indices.clone()              # readable right after the pass
+        other = network.DualGNN().to(dev)
+        with torch.no_grad():
+            other((dv0.shallow_copy(), df0.shallow_copy()))               # another net, same device arena
+        with pytest.raises(GeobiError, match='overwritten by a later forward'):
+            net.gnn_v.pooling1.last_clusters
+        with pytest.raises(GeobiError, match='overwritten by a later forward'):
+            net.gnn_f.pooling2.unpooling_indices
+        assert other.gnn_v.pooling1.unpooling_indices.shape == first.shape
+    finally:
+        executor.ENABLED = was
+    for train in (False, True):
+        for a, b in zip(got[(False, train)], got[(True, train)]):
+            assert torch.equal(a, b)
 
 
 def test_union_of_prebuilt_graphs_equals_coo_union(dev):

@@ -181,17 +181,25 @@ def test_c2_single_patch_meshes_against_oracle(dev, i):
 
 
 _MP_WORKER = r'''
-import os, sys, numpy as np, torch
+import os, sys, time
+T0 = time.time()
+def stamp(what):          # phase times on stderr: a slow run says where it waited (rendezvous, GPU, reduction)
+    print('[rank %%s] %%-22s +%%.1f s' %% (os.environ.get('RANK'), what, time.time() - T0), file=sys.stderr, flush=True)
+import numpy as np, torch
 sys.path.insert(0, %(root)r)
 import torch.distributed as dist
 from geobi_gnn_amd import network, patches, meshgen
 from geobi_gnn_amd.parallel import init_distributed
+stamp('imports')
 rank, world, device = init_distributed()
+stamp('process group (gloo)')
 assert world == 2 and device.type == 'cuda'
 torch.manual_seed(0)
 net = network.DualGNN().to(device).eval()
 noisy, clean, faces = meshgen.noisy_icosphere(20, 0.2, seed=31)            # F = 8000 -> 5 patches of 2000 faces
+stamp('network + mesh')
 out = patches.predict_mesh(net, noisy, faces, sub_size=2000, n_iter=10, gt_points=clean)
+stamp('sharded predict_mesh')
 assert out['n_patches'] >= 4
 if rank == 0:
     solo = patches.predict_mesh(net, noisy, faces, sub_size=2000, n_iter=10, gt_points=clean, distributed=False)
@@ -202,8 +210,10 @@ if rank == 0:
     assert abs(solo['angle1'] - out['angle1']) < 1e-3 and abs(solo['angle2'] - out['angle2']) < 1e-3
 else:
     assert out['Vp'] is None and out['V_updated'] is None
+stamp('single-rank comparison')
 dist.barrier()
 dist.destroy_process_group()
+stamp('done')
 print('rank', rank, 'ok')
 '''
 
@@ -211,18 +221,26 @@ print('rank', rank, 'ok')
 def test_patch_scatter_two_ranks_on_one_device(dev, tmp_path):
     """SURVEY 8e inference sharding, rehearsed with 2 ranks sharing this box's one GPU (gloo): the ranks take
     alternate patches of one mesh, one reduction merges them on rank 0, result == the single-rank run."""
-    import os, subprocess, sys
+    import os, subprocess, sys, time
+    from helpers import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'mp_worker.py'
     script.write_text(_MP_WORKER % {'root': root})
-    env = dict(os.environ, GEOBI_ALL_RANKS_ON_DEVICE0='1', GEOBI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    # gloo looks its interface up by host name, which need not resolve on a GPU box: pin it to the loopback
+    env = dict(os.environ, GEOBI_ALL_RANKS_ON_DEVICE0='1', GEOBI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               GLOO_SOCKET_IFNAME='lo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', '29751', str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(script)]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    phases = '\n'.join(l for l in out.stderr.splitlines() if l.startswith('[rank '))
+    print('two ranks on one device: %.1f s\n%s' % (took, phases))        # shown by pytest -rP / on failure
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
+    assert took < 120, 'two-rank rehearsal took %.0f s:\n%s' % (took, phases)
 
 
 def test_executor_on_open_patches_equals_module_path(dev):

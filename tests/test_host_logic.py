@@ -172,10 +172,12 @@ print('rank', rank, 'ok')
 def test_data_parallel_gloo_world2(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER % {'root': ROOT})
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', OMP_NUM_THREADS='2',
-               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    from helpers import free_port
+    port = str(free_port())
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, OMP_NUM_THREADS='2',
+               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='', GLOO_SOCKET_IFNAME='lo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', '29731', str(script)]
+           '--master-addr', '127.0.0.1', '--master-port', port, str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
@@ -229,10 +231,12 @@ def test_patch_scatter_gloo_world2(tmp_path):
     single-rank sums (partition is exact and disjoint; visit counts bit-equal)."""
     script = tmp_path / 'patch_worker.py'
     script.write_text(_PATCH_WORKER % {'root': ROOT})
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29741', OMP_NUM_THREADS='2',
-               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    from helpers import free_port
+    port = str(free_port())
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, OMP_NUM_THREADS='2',
+               CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='', GLOO_SOCKET_IFNAME='lo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', '29741', str(script)]
+           '--master-addr', '127.0.0.1', '--master-port', port, str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == 2
@@ -391,6 +395,13 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rank_sum'] == 3.0 and out['backend'] == 'gloo'
     assert 'torch.distributed.run' in r.stderr and '--nproc-per-node 2' in r.stderr
+    # the fields that let a scaling line explain itself, produced by the helpers of the real line:
+    # backend + world size, the all-reduce alone, every rank's own step time
+    cfg = out['config']
+    assert cfg['backend'] == 'gloo' and cfg['world_size'] == 2
+    assert cfg['collective_us'] > 0 and 0 < cfg['rank_ms_per_step']['min'] <= cfg['rank_ms_per_step']['max']
+    # three successive mean all-reduces of (1, 2): 1.5 every time
+    assert cfg['bucket_mean'] == 1.5
 
 
 def test_bench_relays_a_failing_child_and_checks_world_size():
