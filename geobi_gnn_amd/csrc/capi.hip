@@ -196,6 +196,8 @@ int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const floa
   return match_heavy_edge(rowptr, col, w, N, rounds, init, cluster, cluster_final, status, ws, ws_bytes, S(stream));
 }
 
+int geobi_set_match_round_cap(int cap) { set_match_round_cap(cap); return 0; }
+
 size_t geobi_match_coarsen_ws_bytes(int64_t N) { return match_coarsen_ws_bytes(N); }
 int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                         int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,

@@ -187,6 +187,7 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
                   bool* rowinfo_made = nullptr);
 int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                      int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, hipStream_t s);
+void set_match_round_cap(int cap);
 size_t relabel_ws_bytes(int64_t N);
 int relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count, void* ws,
                     size_t ws_bytes,

@@ -164,7 +164,8 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
   static thread_local int32_t* pub = nullptr;
   static thread_local int pub_seq = 0;
   if (pub == nullptr) {
-    GEOBI_HIP(hipHostMalloc((void**)&pub, 16 * sizeof(int32_t), hipHostMallocMapped));
+    // portable: visible to every device context of the process, whichever was current at the first call
+    GEOBI_HIP(hipHostMalloc((void**)&pub, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocPortable));
     for (int i = 0; i < 16; ++i) pub[i] = 0;
   }
   auto run_edges = [&](int t, bool publish) {
@@ -187,11 +188,16 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     volatile int32_t* vp = pub;
     long spins = 0;
     bool got = false;
+    // bounded: the stream is polled every 2^14 spins (a fault or an idle stream is noticed within microseconds), and
+    // after ~2^26 spins (seconds) the blocking read below takes over whatever happened to the mapped word
     while (!(got = (__atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq))) {
-      if ((++spins & 0xfffff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {     // the stream ran dry without a word
+      ++spins;
+      if ((spins & 0x3f) == 0) __builtin_ia32_pause();
+      if ((spins & 0x3fff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {        // the stream ran dry without a word
         got = __atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq;
         break;
       }
+      if (spins > (1l << 26)) break;
     }
     if (got) {
       for (int i = 0; i < 8; ++i) h[i] = vp[i];

@@ -34,13 +34,22 @@ namespace {
 using namespace feast_dev;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TN = 32;        // nodes per tile = rows of one MFMA tile
-constexpr int NW = 8;         // waves per workgroup
+// Two tile geometries (template parameter ROWS of the kernels below):
+//   32 rows  8 waves, v_mfma_f32_32x32x2_f32, 74-78 KB of LDS at 64 channels: TWO workgroups per CU
+//   16 rows  4 waves, v_mfma_f32_16x16x4_f32 (same flops per cycle, 32 cycles per instruction, 4-register
+//            accumulators), 37-40 KB: FOUR workgroups per CU -- the same 16 waves, but four independent phase
+//            sequences instead of two, so one tile's matrix phase covers another's gather latency.
+// The packed weights serve both: element (k, col) sits at Bp[k / 4][col][k % 4] (one 16-B load per lane = the lane's
+// k-slot of four consecutive MFMAs); only the padding of K differs (16 covers both).
+constexpr int TN = 32;        // rows of the 32-row geometry (128-channel backward kernel)
+constexpr int NW = 8;
 constexpr int RED_LD = 36;    // row stride of a partial output tile in LDS
-constexpr int G = 16;         // lanes per node in the gather phase: a wave owns 4 nodes, the 8 waves the 32 of a tile
+constexpr int G = 16;         // lanes per node in the gather phase: a wave owns 4 nodes
 constexpr int NPW = 64 / G;
 static_assert(NW * NPW == TN, "one gather pass covers the tile");
+constexpr int KPAD = 16;      // the packed weights' K is padded to whole 16-deep blocks (zero rows)
 
 // Shape of one instantiation.  C = width of the gathered rows; MODE 0: K = 9 C (padded to 8), MODE 1: 9 C + 24.
 // The 16 lanes of a node split the C channels: VEC floats per lane in NP pieces of PV floats (C = 128: two
@@ -49,28 +58,40 @@ static_assert(NW * NPW == TN, "one gather pass covers the tile");
 // C = 128 does not fit a [32][9 C] tile twice into a CU's LDS: the tile then holds HC = 4 heads at a time
 // (3 chunks: 4 + 4 + 1 heads), the node's 9 x VEC accumulators wait in registers, and the MFMA accumulators run
 // across the chunks.
-template <int C, int MODE>
+template <int C, int MODE, int ROWS>
 struct Shape {
+  static constexpr int NWV = ROWS / NPW;                          // waves per workgroup
+  static constexpr int KB = ROWS == 32 ? 8 : 16;                  // depth of one weight block (4 MFMAs)
   static constexpr int VEC = C >= 16 ? C / 16 : 1;
   static constexpr int NP = VEC > 4 ? VEC / 4 : 1;
   static constexpr int PV = VEC / NP;
   static constexpr int ACTIVE = C >= 16 ? 16 : C;                 // lanes of the group that own channels
   static constexpr int HC = C >= 128 ? 4 : H;                     // heads per LDS chunk
   static constexpr int NCHUNK = (H + HC - 1) / HC;
-  static constexpr int KD = MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP;     // K of the whole product
+  static constexpr int KR = MODE == 0 ? H * C : H * C + 2 * HP;   // real columns of a tile row (MODE 1: the r' row)
+  static constexpr int KD = (KR + KB - 1) / KB * KB;              // K of the whole product: whole weight blocks
   static constexpr int KC_FULL = HC * C;                          // chunk width (all but the last chunk)
   static constexpr int KC_LAST = KD - (NCHUNK - 1) * KC_FULL;
+  static constexpr int KR_LAST = KR - (NCHUNK - 1) * KC_FULL;     // real columns of the last chunk
   static constexpr int KC_MAX = NCHUNK == 1 ? KD : (KC_FULL > KC_LAST ? KC_FULL : KC_LAST);
-  static constexpr int LD = (KC_MAX - 4 + 63) / 64 * 64 + 4;      // = 4 mod 64: conflict-free ds_read_b128 of A
+  // row stride: 32 rows: = 4 mod 64, conflict-free ds_read_b128 of A; 16 rows: LD / 4 odd is all 16 rows need (one
+  // 2-way quad remains between the k-slots of a lane group: 36 A reads per wave and tile, immaterial) and keeps the
+  // 64-channel tiles under 40 KB
+  static constexpr int LD = ROWS == 32 ? (KC_MAX - 4 + 63) / 64 * 64 + 4 : KC_MAX + 4;
   static constexpr bool SLOT_IN_ROW = G * HP <= (NCHUNK == 1 ? H * C : KC_FULL);
-  static constexpr int TILE_FLOATS = TN * LD > NW * 32 * RED_LD ? TN * LD : NW * 32 * RED_LD;
-  static constexpr int SLOT_FLOATS = SLOT_IN_ROW ? 0 : NW * 64 * HP;
+  static constexpr int RED_FLOATS = ROWS == 32 ? NW * 32 * RED_LD : 4 * 16 * 36;     // K-split partial tiles
+  static constexpr int TILE_FLOATS = ROWS * LD > RED_FLOATS ? ROWS * LD : RED_FLOATS;
+  static constexpr int SLOT_FLOATS = SLOT_IN_ROW ? 0 : NWV * 64 * HP;
   static_assert(VEC * ACTIVE == C || C < 16, "channel split");
-  static_assert(KD % 8 == 0 && (NCHUNK == 1 || KC_FULL % 8 == 0) && KC_LAST % 8 == 0 && KC_LAST > 0, "whole k-blocks per chunk");
+  static_assert(KD % KB == 0 && (NCHUNK == 1 || KC_FULL % KB == 0) && KC_LAST % KB == 0 && KC_LAST > 0, "whole k-blocks per chunk");
+  static_assert(KC_MAX % 16 == 0 || ROWS == 32, "LD / 4 odd");
 };
-template <int C, int MODE, int LC>
-constexpr int fused_lds_floats() { return Shape<C, MODE>::TILE_FLOATS + Shape<C, MODE>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0); }
-constexpr int fused_k(int C, int MODE) { return MODE == 0 ? (H * C + 7) / 8 * 8 : H * C + 2 * HP; }
+template <int C, int MODE, int LC, int ROWS>
+constexpr int fused_lds_floats() {
+  return Shape<C, MODE, ROWS>::TILE_FLOATS + Shape<C, MODE, ROWS>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0);
+}
+// K of the PACKED weights (both geometries read the same pack): the r' / z row rounded up to 16
+constexpr int fused_k(int C, int MODE) { return ((MODE == 0 ? H * C : H * C + 2 * HP) + KPAD - 1) / KPAD * KPAD; }
 
 #ifdef GEOBI_FUSED_STAMPS
 // Diagnostic build only (tools/build_variant.sh ... -DGEOBI_FUSED_STAMPS): shader-clock stamps of wave 0 of each
@@ -84,16 +105,17 @@ __device__ unsigned long long g_stamps_bwd[16384][8];       // the fused backwar
 #define GEOBI_STAMP_BWD(i) do { } while (0)
 #endif
 
-template <int C, int MODE, int LC, int NT>
-__global__ __launch_bounds__(512, 4) void feast_fused_kernel(
+template <int C, int MODE, int LC, int NT, int ROWS>
+__global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
     const int* __restrict__ deg_rowptr, int N, const float* __restrict__ xl, const float* __restrict__ ul,
     const float* __restrict__ dpd, const float* __restrict__ Bp, int NOUT, const float* __restrict__ bias,
     float slope, float* __restrict__ out, int ldo, float* __restrict__ out1, int split, int ldo1,
     float* __restrict__ tile_out) {
-  using S = Shape<C, MODE>;
+  using S = Shape<C, MODE, ROWS>;
   constexpr int VEC = S::VEC, NP = S::NP, PV = S::PV, LD = S::LD, HC = S::HC, NCHUNK = S::NCHUNK;
+  constexpr int TN = ROWS, NW = S::NWV, NTHREADS = 64 * NW;       // shadow the 32-row constants
   static_assert(NW % NT == 0, "column tiles divide the waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_slots = smem + S::TILE_FLOATS;
@@ -231,12 +253,19 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
   }
 
   // ------------------------------------------------------------------ chunks: registers -> LDS tile -> MFMA
+  // Matrix-phase roles.  32 rows: wave = (column tile ct of 32, k-range ks), one 32 x 32 accumulator.  16 rows: wave =
+  // (column group cg of 32 = two 16-column tiles, k-range ks): two independent 4-register accumulators whose MFMAs
+  // alternate (dependent latency 40 cycles > the 32-cycle issue interval of v_mfma_f32_16x16x4_f32).
   constexpr int KS = NW / NT;
   const int ct = wave % NT, ks = wave / NT;
   const int hf = lane >> 5, l31 = lane & 31;
+  const int kq = lane >> 4, l15 = lane & 15;                      // 16 rows: k-slot and row / column of the lane
   f32x16 macc;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (ROWS == 32) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) macc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) macc[r] = 0.f;
+  }
 
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) {
@@ -253,34 +282,41 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
     }
     if (c == NCHUNK - 1) {
       if constexpr (MODE == 0) {
-        for (int i = nheads * C + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding (C = 6 / 12)
+        for (int i = nheads * C + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding
       } else {
         if (k < 6) {                                                                // [dp | dcs]: 24 floats
           float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
           if (valid) t = reinterpret_cast<const float4*>(dpd + (size_t)node * (2 * HP))[k];
           reinterpret_cast<float4*>(zrow + nheads * C)[k] = t;
         }
+        for (int i = S::KR_LAST + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding behind them
       }
     }
     // ---- tile chunk x packed weights on the matrix cores.  The weights of a wave's k-range come from L2 in
-    // batches of BATCH k-blocks (one 16-B load per lane and block = 4 MFMAs): the first batch is requested BEFORE
-    // the barrier that publishes the tile, every further one a whole batch (256 BATCH pipe cycles) ahead of its
-    // use, so the matrix pipe never waits on L2 latency; the A operand is read from LDS one block ahead.
+    // batches of BATCH k-blocks (one 16-B load per lane and block = 4 MFMAs per tile): the first batch is requested
+    // BEFORE the barrier that publishes the tile, every further one a whole batch ahead of its use, so the matrix pipe
+    // never waits on L2 latency; the A operand is read from LDS one block ahead.
     {
-      constexpr int BATCH = VEC >= 8 ? 4 : 8;
-      const int nkb = ((c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL) / 8;
-      const int kb_base = c * (S::KC_FULL / 8);
+      constexpr int KB = S::KB;
+      constexpr int BATCH = ROWS == 32 ? (VEC >= 8 ? 4 : 8) : (VEC >= 8 ? 2 : 4);
+      constexpr int WPB = ROWS == 32 ? 1 : 2;                      // weight loads per block (column tiles per wave)
+      constexpr int BSTR = (KB / 4) * 32 * NT;                     // float4 per weight block
+      const int nkb = ((c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL) / KB;
+      const int kb_base = c * (S::KC_FULL / KB);
       const int kb_per = (nkb + KS - 1) / KS;
       const int kb0 = ks * kb_per;
       const int kb1 = min(nkb, kb0 + kb_per);
       const bool work = kb0 < kb1;
-      const float* arow = smem + l31 * LD + 4 * hf;
-      const float4* bcol = reinterpret_cast<const float4*>(Bp) + (size_t)kb_base * (2 * 32 * NT) +
-                           (size_t)hf * (32 * NT) + ct * 32 + l31;
-      float4 w_cur[BATCH], w_nxt[BATCH];
-      auto load_w = [&](float4 (&wv)[BATCH], int b) {
+      const float* arow = ROWS == 32 ? smem + l31 * LD + 4 * hf : smem + l15 * LD + 4 * kq;
+      const float4* bcol = reinterpret_cast<const float4*>(Bp) + (size_t)kb_base * BSTR +
+                           (ROWS == 32 ? (size_t)hf * (32 * NT) + ct * 32 + l31
+                                       : (size_t)kq * (32 * NT) + ct * 32 + l15);
+      float4 w_cur[BATCH][WPB], w_nxt[BATCH][WPB];
+      auto load_w = [&](float4 (&wv)[BATCH][WPB], int b) {
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) wv[u] = bcol[(size_t)min(b + u, kb1 - 1) * (2 * 32 * NT)];
+        for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) wv[u][j] = bcol[(size_t)min(b + u, kb1 - 1) * BSTR + 16 * j];
       };
       if (work) load_w(w_cur, kb0);
       GEOBI_STAMP(3);
@@ -288,33 +324,46 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
       GEOBI_STAMP(4);
       if (tile_out != nullptr) {
         // the tile rows themselves (MODE 1: r' = [r | dp | dcs]) for the weight-gradient GEMM [x | 1]^T r'
-        const int kc = (c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL;
+        const int kc = (c == NCHUNK - 1) ? S::KR_LAST : S::KC_FULL;
         const int q4 = kc >> 2;                                    // float4 per row of this chunk
-        for (int i = threadIdx.x; i < TN * q4; i += 512) {
+        for (int i = threadIdx.x; i < TN * q4; i += NTHREADS) {
           const int r = i / q4, c4 = (i - r * q4) * 4;
           const int gn = tile * TN + r;
           if (gn < N)
-            *reinterpret_cast<float4*>(tile_out + (size_t)gn * S::KD + c * S::KC_FULL + c4) =
+            *reinterpret_cast<float4*>(tile_out + (size_t)gn * S::KR + c * S::KC_FULL + c4) =
                 *reinterpret_cast<const float4*>(smem + r * LD + c4);
         }
       }
       if (work) {
-        float4 a = *reinterpret_cast<const float4*>(arow + 8 * kb0);
+        float4 a = *reinterpret_cast<const float4*>(arow + KB * kb0);
         for (int b = kb0; b < kb1; b += BATCH) {
           load_w(w_nxt, b + BATCH);                 // clamped: always a valid address
 #pragma unroll
           for (int u = 0; u < BATCH; ++u) {
-            const float4 an = *reinterpret_cast<const float4*>(arow + 8 * min(b + u + 1, kb1 - 1));
+            const float4 an = *reinterpret_cast<const float4*>(arow + KB * min(b + u + 1, kb1 - 1));
             if (b + u < kb1) {
-              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w_cur[u].x, macc, 0, 0, 0);
-              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w_cur[u].y, macc, 0, 0, 0);
-              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w_cur[u].z, macc, 0, 0, 0);
-              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w_cur[u].w, macc, 0, 0, 0);
+              if constexpr (ROWS == 32) {
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w_cur[u][0].x, macc, 0, 0, 0);
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w_cur[u][0].y, macc, 0, 0, 0);
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w_cur[u][0].z, macc, 0, 0, 0);
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w_cur[u][0].w, macc, 0, 0, 0);
+              } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w_cur[u][0].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w_cur[u][WPB - 1].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w_cur[u][0].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w_cur[u][WPB - 1].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w_cur[u][0].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w_cur[u][WPB - 1].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w_cur[u][0].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w_cur[u][WPB - 1].w, acc1, 0, 0, 0);
+              }
             }
             a = an;
           }
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) w_cur[u] = w_nxt[u];
+          for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) w_cur[u][j] = w_nxt[u][j];
         }
       }
     }
@@ -322,9 +371,20 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
     __syncthreads();                               // every wave is done reading this chunk of the tile
     GEOBI_STAMP(6);
   }
-  float(*red)[32][RED_LD] = reinterpret_cast<float(*)[32][RED_LD]>(smem);
+  // ---- partial tiles of the K splits -> LDS.  C/D layouts: 32 x 32: row (r & 3) + 8 (r >> 2) + 4 hf, column l31;
+  // 16 x 16: row 4 kq + r, column l15
+  constexpr int RLD = ROWS == 32 ? RED_LD : 36;
+  float(*red)[TN][RLD] = reinterpret_cast<float(*)[TN][RLD]>(smem);
+  if constexpr (ROWS == 32) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][l31] = macc[r];
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][l31] = macc[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][4 * kq + r][l15] = acc0[r];
+      red[wave][4 * kq + r][16 + l15] = acc1[r];
+    }
+  }
   __syncthreads();
 
   // ------------------------------------------------------------------ epilogue: fold the K splits, store
@@ -371,26 +431,22 @@ __global__ __launch_bounds__(512, 4) void feast_fused_kernel(
 // (78 KB of LDS each); 16 = half-used MFMA tiles, 4 waves, FOUR workgroups per CU (39 KB each) whose phases interleave
 // better -- but the matrix phase then does twice the MFMA work per node, and that costs more than the interleaving
 // gains: 262 against 265 M-edges/s in a same-box A/B (tools/ab_lib.sh).  32 is the product build.
-#ifndef GEOBI_K2_ROWS
-#define GEOBI_K2_ROWS 32
-#endif
-constexpr int RT = GEOBI_K2_ROWS;
-constexpr int KW = RT / NPW;           // waves per workgroup
-constexpr int KT = 64 * KW;            // threads per workgroup
-static_assert(RT == 32 || RT == 16, "a tile is one MFMA tile or half of one");
-
-template <int C, int LC, int COUT>
-__global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
+// (Round 2 tried 16 rows on HALF-USED 32 x 32 MFMA tiles: twice the matrix work per node, no gain.  The 16-row form below
+// runs on v_mfma_f32_16x16x4_f32: same matrix work per node as the 32-row form.)
+template <int C, int LC, int COUT, int RT>
+__global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
     const float* __restrict__ ul, const float* __restrict__ gout, const float* __restrict__ out_act, float slope,
     const float* __restrict__ Wf, int Kp, float* __restrict__ g_out, float* __restrict__ dl, float* __restrict__ dpn,
     float* __restrict__ dcs, int ld_dcs) {
   constexpr int K = H * C;
+  constexpr int KW = RT / NPW, KT = 64 * KW;     // waves / threads per workgroup
   constexpr int NCT = (K + 31) / 32;             // 32-column tiles of dz
   constexpr int LDZ = NCT * 32 + 4;              // + 4: the four node groups of a wave read distinct bank quads
   constexpr int GL = COUT + 4;                   // g tile row stride: conflict-free ds_read_b128 of the A operand
   static_assert(C <= 64, "one chunk");
+  static_assert(RT == 32 || RT == 16, "a tile is one 32 x 32 MFMA tile or a row of 16 x 16 tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_g = smem;                             // [RT][GL]
   float* s_z = smem + RT * GL;                   // [RT][LDZ]
@@ -425,17 +481,16 @@ __global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
   GEOBI_STAMP_BWD(1);
 
   // ---- matrix phase: dz[RT, K] = g[RT, COUT] Wf^T; wave w owns column tiles w, w + KW, w + 2 KW, ...
-  // The weights of up to three of a wave's tiles are requested together, four k-blocks at a time: one exposed load
-  // latency per batch instead of one per tile.  RT = 16: the A operand's rows 16..31 repeat rows 0..15 and the
-  // accumulator rows >= 16 (registers 8..15) are dropped.
-  {
+  if constexpr (RT == 32) {
+    // The weights of up to three of a wave's tiles are requested together, four k-blocks at a time: one exposed load
+    // latency per batch instead of one per tile.
     const int hf = lane >> 5, l31 = lane & 31;
     constexpr int NKB = COUT / 8;
     constexpr int MAXT = (NCT + KW - 1) / KW;                      // column tiles per wave
     constexpr int TB = MAXT < 3 ? MAXT : 3;                        // tiles per round (48 accumulator registers)
     constexpr int HB = 4;                                          // k-blocks per batch of weight loads
     static_assert(NKB % HB == 0, "whole batches");
-    const float* arow = s_g + (l31 % RT) * GL + 4 * hf;
+    const float* arow = s_g + l31 * GL + 4 * hf;
 #pragma unroll
     for (int t0 = 0; t0 < MAXT; t0 += TB) {
       const float* brow[TB];
@@ -472,8 +527,76 @@ __global__ __launch_bounds__(KT, 4) void feast_rowpass_fused_kernel(
         const int ct = wave + (t0 + t) * KW;
         if (ct < NCT) {
 #pragma unroll
-          for (int r = 0; r < (RT == 32 ? 16 : 8); ++r)
+          for (int r = 0; r < 16; ++r)
             s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + ct * 32 + l31] = acc[t][r];
+        }
+      }
+    }
+  } else {
+    // 16 rows: 16-column tiles on v_mfma_f32_16x16x4_f32, lane = (row / column l15, k-slot kq); a lane's 16-B load of
+    // Wf row (ct 16 + l15) at k = 16 kb + 4 kq feeds four MFMAs, the matching A operand is the g tile's
+    // [l15][16 kb + 4 kq ..].  A wave's tiles are independent accumulator chains (TB per round, their MFMAs interleaved:
+    // dependent latency 40 cycles against a 32-cycle issue interval).
+    const int kq = lane >> 4, l15 = lane & 15;
+    constexpr int NCT16 = (K + 15) / 16;
+    constexpr int NKB = COUT / 16;                                 // 16-deep k-blocks
+    constexpr int MAXT = (NCT16 + KW - 1) / KW;                    // column tiles per wave
+    constexpr int TB = MAXT <= 9 ? MAXT : 5;                       // tiles per round (all of them up to 64 channels)
+    constexpr int HB = TB > 5 ? 1 : (NKB < 2 ? NKB : 2);           // k-blocks per batch of weight loads
+    constexpr int NB = NKB / HB;
+    static_assert(NKB % HB == 0, "whole batches");
+    const float* arow = s_g + l15 * GL + 4 * kq;
+#pragma unroll
+    for (int t0 = 0; t0 < MAXT; t0 += TB) {
+      const float* brow[TB];
+      f32x4 acc[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        const int ct = wave + (t0 + t) * KW;
+        const int krow = min(ct * 16 + l15, Kp - 1);               // rows past K: clamped, their columns are never read
+        brow[t] = Wf + (size_t)krow * COUT + 4 * kq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+      }
+      // the next batch's weights are requested before the current batch's MFMAs (36 x 32 cycles cover an L2 round trip)
+      float4 w[TB][HB], wn[TB][HB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t)
+#pragma unroll
+        for (int u = 0; u < HB; ++u) w[t][u] = *reinterpret_cast<const float4*>(brow[t] + 16 * u);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int u = 0; u < HB; ++u) wn[t][u] = *reinterpret_cast<const float4*>(brow[t] + 16 * ((b + 1) * HB + u));
+        }
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (b * HB + u));
+#pragma unroll
+          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t][u].x, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t][u].y, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t][u].z, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t][u].w, acc[t], 0, 0, 0);
+        }
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int u = 0; u < HB; ++u) w[t][u] = wn[t][u];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        const int ct = wave + (t0 + t) * KW;
+        if (ct < NCT16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_z[(4 * kq + r) * LDZ + ct * 16 + l15] = acc[t][r];
         }
       }
     }
@@ -832,20 +955,28 @@ __global__ void pack_fused_batch_kernel(PackBatch pb) {
   }
 }
 
-template <int C, int MODE, int LC, int NT>
+// Tile geometry of the fused kernels: GEOBI_TILE16 (read once): 1 = 16-row tiles / four workgroups per CU (default),
+// 0 = 32-row tiles / two workgroups per CU.  Same-box A/B knob; both forms stay under the parity tests.
+bool tile16() {
+  static const bool on = [] { const char* f = getenv("GEOBI_TILE16"); return !f || atoi(f) != 0; }();
+  return on;
+}
+
+template <int C, int MODE, int LC, int NT, int ROWS>
 int launch_one(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
                const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
                int ldo1, float* tile_out, hipStream_t s) {
-  constexpr size_t lds = (size_t)fused_lds_floats<C, MODE, LC>() * sizeof(float);
+  constexpr size_t lds = (size_t)fused_lds_floats<C, MODE, LC, ROWS>() * sizeof(float);
   static_assert(lds <= 163840, "tile exceeds the LDS of a CU");
+  static_assert(ROWS == 32 || lds <= 40960, "16-row tiles: four workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT, ROWS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_fused_kernel<C, MODE, LC, NT><<<xcd_grid(cdiv(N, TN)), 512, lds, s>>>(
+  feast_fused_kernel<C, MODE, LC, NT, ROWS><<<xcd_grid(cdiv(N, ROWS)), 16 * ROWS, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1,
       tile_out);
   GEOBI_LAUNCH_OK();
@@ -863,10 +994,18 @@ int launch_nt(int NT, const float* xa, const float* xb, int Ca, const float* p, 
               int ldo1, float* tile_out, hipStream_t s) {
   // dx with per-edge logits writes a 6- or 12-channel input gradient: one column tile
   constexpr bool kNarrowOnly = MODE == 1 && LC > 0;
-  if (NT == 1) return launch_one<C, MODE, LC, 1>(GEOBI_FUSED_ARGS);
-  if constexpr (!kNarrowOnly) {
-    if (NT == 2) return launch_one<C, MODE, LC, 2>(GEOBI_FUSED_ARGS);
-    if (NT == 4) return launch_one<C, MODE, LC, 4>(GEOBI_FUSED_ARGS);
+  if (tile16()) {
+    if (NT == 1) return launch_one<C, MODE, LC, 1, 16>(GEOBI_FUSED_ARGS);
+    if constexpr (!kNarrowOnly) {
+      if (NT == 2) return launch_one<C, MODE, LC, 2, 16>(GEOBI_FUSED_ARGS);
+      if (NT == 4) return launch_one<C, MODE, LC, 4, 16>(GEOBI_FUSED_ARGS);
+    }
+  } else {
+    if (NT == 1) return launch_one<C, MODE, LC, 1, 32>(GEOBI_FUSED_ARGS);
+    if constexpr (!kNarrowOnly) {
+      if (NT == 2) return launch_one<C, MODE, LC, 2, 32>(GEOBI_FUSED_ARGS);
+      if (NT == 4) return launch_one<C, MODE, LC, 4, 32>(GEOBI_FUSED_ARGS);
+    }
   }
   return set_error("feast fused: unsupported output width %d", NOUT);
 }
@@ -883,8 +1022,8 @@ extern "C" int geobi_debug_stamps_bwd(void* host_dst, size_t bytes) {
 #endif
 
 namespace {
-template <int C, int LC, int COUT>
-int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
+template <int C, int LC, int COUT, int RT>
+int launch_rowpass_fused_rt(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                          const int* col, int N, const float* ul, const float* gout, const float* out_act, float slope,
                          const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
                          hipStream_t s) {
@@ -894,14 +1033,26 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
   static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
   static bool attr_set = false;
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT, RT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_rowpass_fused_kernel<C, LC, COUT><<<xcd_grid(cdiv(N, RT)), KT, lds, s>>>(
+  feast_rowpass_fused_kernel<C, LC, COUT, RT><<<xcd_grid(cdiv(N, RT)), 16 * RT, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp, g_out, dl, dpn, dcs, ld_dcs);
   GEOBI_LAUNCH_OK();
   return 0;
+}
+
+template <int C, int LC, int COUT>
+int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
+                         const int* col, int N, const float* ul, const float* gout, const float* out_act, float slope,
+                         const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
+                         hipStream_t s) {
+  if (tile16())
+    return launch_rowpass_fused_rt<C, LC, COUT, 16>(xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp,
+                                                    g_out, dl, dpn, dcs, ld_dcs, s);
+  return launch_rowpass_fused_rt<C, LC, COUT, 32>(xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp,
+                                                  g_out, dl, dpn, dcs, ld_dcs, s);
 }
 }  // namespace
 

@@ -1130,9 +1130,19 @@ int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s)
 
 // `rounds` proposal rounds; the first one initialises the state (init != 0) and the undecided counter.
 // On return pp holds the proposals of the last round.
+// Test hook (geobi_set_match_round_cap): at most cap x (rounds / 8) rounds per call.  The callers ask for 8 rounds and
+// double the number on every resume of their repair loops; a cap of 1 makes those 1, 2, 4, ... -- every pooling step then
+// comes back with undecided nodes and is resumed, which an uncapped mesh graph almost never needs.
+static int g_round_cap = 0;
+void set_match_round_cap(int cap) { g_round_cap = cap > 0 ? cap : 0; }
+
 static void launch_match_rounds(const int32_t* rowptr, const int32_t* col, const float* w, int N, int rounds, int init,
                                 int32_t* cluster, int32_t* status, int*& pp, int*& pn, hipStream_t s) {
   const int blocks = cdiv(N, 256);
+  if (g_round_cap > 0) {
+    const int64_t capped = (int64_t)g_round_cap * (rounds > 8 ? rounds / 8 : 1);
+    if (capped < rounds) rounds = (int)capped;
+  }
   for (int r = 0; r < rounds; ++r) {
     if (r > 0)
       match_round_kernel<0><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);

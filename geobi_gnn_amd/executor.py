@@ -214,9 +214,11 @@ def forward(net, data_v, data_f):
     V, F = lv_v.N, lv_f.N
     verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
     normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
-    # the forward's side effect on its input (network.py:337: data_f.x = cat(x_f, centroid, normal)), as the module
-    # path leaves it; copied out because the arena is reused by the next pass
-    data_f.x = _views(arena, out.xf_off, F * 12, torch.float32).view(F, 12).clone()
+    # NOT reproduced: the reference's forward rewrites its input bags (network.py:271,298,337 leave data_v.x /
+    # data_f.x as intermediate activations; the module path leaves the l_conv1 outputs there).  No caller of the
+    # reference reads them back (train_dual.py:203-208, test_dual.py:21), and copying two [N, 32] activations out of
+    # the arena per pass would cost more than the heads.  The executor leaves data_v.x / data_f.x as given; the
+    # coupled facet features [F, 12] of network.py:337 are at `xf_off` of the arena for a caller that wants them.
     key = (dev.type, dev.index)
     _GENERATION[key] = _GENERATION.get(key, 0) + 1
     _set_module_state(net, arena, out, (key, _GENERATION[key]))
@@ -329,11 +331,10 @@ def forward_train(net, data_v, data_f):
     _LEARNED[shape_key] = int(1.05 * int(out.used_bytes)) + (16 << 20)
     STATS['train_arena_bytes'], STATS['train_need_bytes'] = nbytes, int(out.used_bytes)
     V, F = lv_v.N, lv_f.N
-    # results are COPIED out (three small tensors): a view would pin the whole training arena (GBs) for as long as the
+    # results are COPIED out (two small tensors): a view would pin the whole training arena (GBs) for as long as the
     # caller keeps the prediction, and the next step's arena could not reuse the block
     verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
     normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
-    data_f.x = _views(arena, out.xf_off, F * 12, torch.float32).view(F, 12).clone()        # network.py:337
     # the pooling modules' state stays a set of views into this pass' own arena (valid, but the block is held until
     # the next training forward drops them -- before it allocates, see _clear_module_state -- so never two arenas)
     _set_module_state(net, arena, out)

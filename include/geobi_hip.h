@@ -134,6 +134,10 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
 size_t geobi_match_ws_bytes(int64_t N);
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+/* test hook: at most cap x (rounds / 8) proposal rounds per call (<= 0: no cap).  With cap = 1 the default 8 rounds
+ * become 1 and every resume of a caller's repair loop (rounds doubled each time) 2, 4, ...: the resume paths of
+ * PoolingLayer.forward / geobi_net_forward run on graphs that otherwise converge at once. */
+int geobi_set_match_round_cap(int cap);
 /* geobi_match_coarsen: the integer front end of one pooling step (code/net_util.py:127-128 plus the inverse
  * lists the feature pooling needs) in one call: the rounds of geobi_match_heavy_edge, then dense ids and
  * segment lists of the matching -- the results of geobi_relabel_compact and geobi_segment_csr_pairs, with

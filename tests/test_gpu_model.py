@@ -613,8 +613,9 @@ def test_malformed_bags_raise_instead_of_reaching_the_device(dev):
 
 
 def test_executor_side_effects_match_the_module_path(dev):
-    """(1) the reference's forward leaves data_f.x = cat(x_f, centroid, normal) (network.py:337): the
-    executor does too, with the same numbers as the module path; (2) predictions are copies, not views that pin the
+    """(1) side effects on the input bags: the module path rewrites data.x like the reference's GNNModule
+    does (network.py:271: the l_conv1 output is left there), the executor leaves the bags as given (documented in
+    executor.forward); predictions are bit-identical either way; (2) predictions are copies, not views that pin the
     arena; (3) pooling state of an inference pass is refused once a later pass has overwritten the shared arena."""
     from geobi_gnn_amd import network, meshgen, executor
     from geobi_gnn_amd._lib import GeobiError
@@ -634,13 +635,14 @@ def test_executor_side_effects_match_the_module_path(dev):
                 else:
                     with torch.no_grad():
                         vp, npred, _ = net((dv, df))
-                assert df.x.shape == (df0.x.shape[0], 12)
-                got[(on, train)] = (df.x.clone(), vp.detach().clone(), npred.detach().clone())
+                got[(on, train)] = (vp.detach().clone(), npred.detach().clone())
                 if on:
+                    assert df.x is df0.x and dv.x is dv0.x                 # bags untouched
                     # copies: a prediction owns V * 3 / F * 3 floats, not the arena
                     assert vp.untyped_storage().nbytes() == vp.numel() * 4
                     assert npred.untyped_storage().nbytes() == npred.numel() * 4
-                    assert df.x.untyped_storage().nbytes() == df.x.numel() * 4
+                else:
+                    assert df.x.shape == (df0.x.shape[0], 32) and dv.x.shape == (dv0.x.shape[0], 32)
         executor.ENABLED = True
         with torch.no_grad():
             net((dv0.shallow_copy(), df0.shallow_copy()))
@@ -1059,3 +1061,72 @@ def test_training_executor_equals_op_tape(dev, n, pool_type, force_depth):
     assert torch.equal(acc_exec, flat.bucket.flat)
     ref = torch.cat([g0[k].flatten() for k, _ in net.named_parameters()])
     assert torch.equal(acc_exec, ref + ref)
+
+
+def _fan_mesh(spokes=150, rings=3):
+    """A disc whose centre vertex has `spokes` incident faces: facet-graph rows of ~`spokes` entries, i.e. coarse rows far
+    beyond the 64 entries the sort-free edge coarsening merges per node."""
+    import numpy as np
+    pts = [[0.0, 0.0, 0.0]]
+    for r in range(1, rings + 1):
+        for k in range(spokes):
+            a = 2 * np.pi * (k + 0.5 * (r % 2)) / spokes
+            pts.append([r * np.cos(a), r * np.sin(a), 0.05 * np.sin(3 * a) * r])
+    faces = []
+    ring = lambda r, k: 1 + (r - 1) * spokes + (k % spokes)
+    for k in range(spokes):
+        faces.append([0, ring(1, k), ring(1, k + 1)])
+    for r in range(1, rings):
+        for k in range(spokes):
+            faces.append([ring(r, k), ring(r + 1, k), ring(r, k + 1)])
+            faces.append([ring(r, k + 1), ring(r + 1, k), ring(r + 1, k + 1)])
+    return np.asarray(pts, dtype=np.float32), np.asarray(faces, dtype=np.int64)
+
+
+@pytest.mark.parametrize('case', ['capped_rounds', 'wide_rows', 'both'])
+def test_executor_repairs_inside_pool_layer(dev, case):
+    """the repair loop of executor.hip:pool_layer under test.  `capped_rounds`: the matching is capped at one
+    proposal round per call (geobi_set_match_round_cap), so every pooling step comes back with undecided nodes and is
+    resumed (twice the rounds each time) until it converges; `wide_rows`: a fan mesh whose hub gives coarse rows wider
+    than the sort-free 64 entries, so those steps are redone by the radix-sort edge coarsening.  Either way the pass
+    stays inside the executor (no fallback) and is bit-identical to the module-by-module path, which repairs in Python."""
+    from geobi_gnn_amd import network, meshgen, executor, _lib as L
+    torch.manual_seed(3)
+    net = network.DualGNN().to(dev).eval()
+    if case == 'capped_rounds':
+        dv, df = meshgen.synthetic_dual_data(9, 0.2, seed=3)
+    else:
+        pts, faces = _fan_mesh()
+        dv, df = meshgen.build_dual_data(pts, faces, pts, name='fan')
+    dv, df = dv.to(dev), df.to(dev)
+    mods = (net.gnn_v.pooling1, net.gnn_v.pooling2, net.gnn_f.pooling1, net.gnn_f.pooling2)
+
+    def run(enabled):
+        was = executor.ENABLED
+        executor.ENABLED = enabled
+        try:
+            with torch.no_grad():
+                vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+            return vp.clone(), npred.clone(), [[c.clone() for c in m.last_clusters] for m in mods]
+        finally:
+            executor.ENABLED = was
+    plain = run(False)                                   # module path, nothing capped: the reference result
+    try:
+        if case != 'wide_rows':
+            L.lib().geobi_set_match_round_cap(1)
+        before = dict(executor.STATS)
+        fast = run(True)
+        slow = run(False)                                # the module path's own repair loop (net_util._coarsen)
+        assert executor.STATS['calls'] == before['calls'] + 1 and executor.STATS['fallback'] == before['fallback']
+    finally:
+        L.lib().geobi_set_match_round_cap(0)
+    for other in (fast, slow):
+        assert torch.equal(other[0], plain[0]) and torch.equal(other[1], plain[1])
+        for la, lb in zip(other[2], plain[2]):
+            for a, b in zip(la, lb):
+                assert torch.equal(a, b)
+    if case != 'capped_rounds':
+        # the fan really exceeds the sort-free width: the hub's facet row alone has > 64 entries
+        g = df.graph()
+        deg = (g.rowptr_out[1:] - g.rowptr_out[:-1]).max().item()
+        assert deg > 64
