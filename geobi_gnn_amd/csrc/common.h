@@ -153,9 +153,11 @@ struct TnOutput {
   float* C4 = nullptr;
   int col0 = 0;
 };
-// I, J: logical output sizes INCLUDING an implicit ones row / column when ones_row / ones_col >= 0
+// I, J: logical output sizes INCLUDING an implicit ones row / column when ones_row / ones_col >= 0, or the column-sums
+// row (sum_row == I - 1: the sums of B's columns over the M rows, formed on the VALU beside the MFMAs; TnOutput.extra_row
+// routes it).
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
-            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s);
+            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s, int sum_row = -1);
 size_t colsum_ws_bytes(int64_t M, int J);
 int colsum(const float* A, int lda, int64_t M, int J, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 

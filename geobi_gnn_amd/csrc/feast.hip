@@ -494,47 +494,6 @@ __global__ void feast_du_final_kernel(const float* __restrict__ partial, int blo
   *dst = accumulate ? *dst + s : s;
 }
 
-// Column sums  bias.grad = sum_i g_i  and  c.grad = sum_i dcs_i  of a layer (fused backward: the weight-gradient
-// GEMM x^T r' then needs no ones row, which would cost a whole extra 32-row MFMA tile).  Fixed-order partial sums
-// per block, one wave per output in the final pass (deterministic).
-__global__ __launch_bounds__(256) void feast_colsums_partial_kernel(const float* __restrict__ g, int Cout,
-                                                                    const float* __restrict__ dcs, int ld_dcs, int N,
-                                                                    int rows_per_block, int CP, float* __restrict__ partial) {
-  __shared__ float red[256];
-  const int CT = Cout + H;
-  const int rows_par = 256 / CP;
-  const int rr = threadIdx.x / CP, jc = threadIdx.x % CP;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(N, r0 + rows_per_block);
-  float s = 0.f;
-  if (jc < CT) {
-    const float* src = jc < Cout ? g + jc : dcs + (jc - Cout);
-    const int ld = jc < Cout ? Cout : ld_dcs;
-#pragma unroll 8
-    for (int r = r0 + rr; r < r1; r += rows_par) s += src[(size_t)r * ld];
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (rr == 0 && jc < CT) {
-    float t = 0.f;
-    for (int q = 0; q < rows_par; ++q) t += red[q * CP + jc];
-    partial[(size_t)blockIdx.x * CT + jc] = t;
-  }
-}
-
-__global__ void feast_colsums_final_kernel(const float* __restrict__ partial, int blocks, int Cout, int accumulate,
-                                           float* __restrict__ dbias, float* __restrict__ dc) {
-  const int CT = Cout + H;
-  const int t = blockIdx.x, lane = threadIdx.x;
-  float s = 0.f;
-  for (int b = lane; b < blocks; b += 64) s += partial[(size_t)b * CT + t];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane != 0) return;
-  float* dst = t < Cout ? dbias + t : (dc ? dc + (t - Cout) : nullptr);
-  if (dst) *dst = accumulate ? *dst + s : s;
-}
-
 // ------------------------------------------------------------------------- small helpers
 __global__ void pack_wf_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int Kp, float* __restrict__ wf) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -982,25 +941,16 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     // feast_du_edge_kernel above instead)
     GEOBI_TRY(side_wait_main(fk, s));
     hipStream_t ss = fk.side ? fk.side : s;
+    // bias.grad and (node-level layers) c.grad ride along as the column sums of r' (one more logical row of the
+    // product, formed on the VALU inside the GEMM: no column-sum kernels, no ones row on the matrix cores)
     TnOutput o;
     o.mode = TN_RPRIME; o.C = dlin_w; o.C3 = LC ? nullptr : du_w;
-    o.Cin = Cin; o.Cout = Cout; o.col0 = 0; o.extra_row = 0; o.accumulate = accumulate;
-    GEOBI_TRY(gemm_tn(xa, Ca_, b.rp, ldr, N, Ca_, ldr, -1, -1, o, b.tn_ws3, b.tn_bytes3, ss));
+    o.C2 = dbias; o.C4 = LC ? nullptr : dc; o.extra_row = 1;
+    o.Cin = Cin; o.Cout = Cout; o.col0 = 0; o.accumulate = accumulate;
+    GEOBI_TRY(gemm_tn(xa, Ca_, b.rp, ldr, N, Ca_ + 1, ldr, -1, -1, o, b.tn_ws3, b.tn_bytes3, ss, Ca_));
     if (Cb) {
-      o.col0 = Ca;
+      o.col0 = Ca; o.extra_row = 0; o.C2 = nullptr; o.C4 = nullptr;
       GEOBI_TRY(gemm_tn(xb, Cb, b.rp, ldr, N, Cb, ldr, -1, -1, o, b.tn_ws3, b.tn_bytes3, ss));
-    }
-    {   // bias.grad and (node-level layers) c.grad: column sums of g and dcs
-      const int CT = Cout + H, CP = CT <= 64 ? 64 : (CT <= 128 ? 128 : 256);
-      int blocks = cdiv(N, 128);                         // 32-64 rows per thread row-lane: many short blocks
-      if (blocks > 2048) blocks = 2048;
-      const int rpb = cdiv(N, blocks);
-      float* partial = (float*)b.tn_ws2;
-      GEOBI_REQUIRE((size_t)blocks * CT * sizeof(float) <= b.tn_bytes2, "feast_bwd: column-sum workspace too small");
-      feast_colsums_partial_kernel<<<blocks, 256, 0, ss>>>(g, Cout, dpd + HP, ld_dpd, (int)N, rpb, CP, partial);
-      GEOBI_LAUNCH_OK();
-      feast_colsums_final_kernel<<<CT, 64, 0, ss>>>(partial, blocks, Cout, accumulate, dbias, LC ? nullptr : dc);
-      GEOBI_LAUNCH_OK();
     }
   } else if (dxa != nullptr) {
     prof_begin(PROF_AGG_BWD, s, feast_agg_bytes(N, Ecap, Cout, H * Cout), Cout);

@@ -276,6 +276,48 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slic
 }
 
 // ------------------------------------------------------------------------------ TN
+// Where output element (i, j) of a TN product goes (the unpacking that used to be a kernel of its own).
+__device__ __forceinline__ void tn_emit(const TnOutput& o, int i, int j, int I, int J, float s) {
+  float* dst = nullptr;
+  if (o.mode == TN_PLAIN) {
+    // an implicit ones row / column (always the last one) lands in C2
+    if (o.extra_row && i == I - 1) { if (!(o.extra_col && j == J - 1)) dst = o.C2 + j; }
+    else if (o.extra_col && j == J - 1) dst = o.C2 + i;
+    else dst = o.C + (size_t)i * o.ldc + j;
+  } else if (o.mode == TN_LIN_UNPACK) {
+    // rows are (head h, in-channel k) of the packed weight, columns are out-channels:
+    // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`); the implicit ones row
+    // (i == I - 1) carries the bias gradient
+    if (i == I - 1) dst = o.C2 + j;
+    else {
+      int h = i / o.Cin, k = i % o.Cin;
+      if (h < GEOBI_H) dst = o.C + ((size_t)h * o.Cout + j) * o.Cin + k;
+    }
+  } else if (o.mode == TN_RPRIME) {
+    // rows: input channels (+ the column-sums row when extra_row), columns: r' = [r (9 Cout) | dp 9 + 3 | dcs 9 + 3]
+    //   data row i, j < 9 Cout            -> lin.weight.grad[j, col0 + i]        (j = h Cout + o)
+    //   data row i, 9 Cout <= j < +9      -> u.weight.grad[j - 9 Cout, col0 + i]
+    //   sums row,   j in the dcs columns  -> c.grad[h]
+    //   sums row,   j < 9 Cout            -> bias.grad[c] = sum_h (sums row)[h Cout + c]: the extra block of
+    //                                        tn_reduce_kernel (sum_h sum_j q_ijh / deg_i = 1: the r columns of a channel
+    //                                        add up to the column sum of g)
+    const int HC = GEOBI_H * o.Cout;
+    const bool sums = o.extra_row && i == I - 1;
+    if (!sums) {
+      if (j < HC) dst = o.C + ((size_t)j * o.Cin + o.col0 + i);
+      else if (j < HC + GEOBI_H && o.C3 != nullptr) dst = o.C3 + ((size_t)(j - HC) * o.Cin + o.col0 + i);
+    } else if (j >= HC + GEOBI_HP && j < HC + GEOBI_HP + GEOBI_H) {
+      if (o.C4 != nullptr) dst = o.C4 + (j - HC - GEOBI_HP);
+    }
+  } else {
+    // TN_DU_DC: A = [dp (rows 0..8) | pad | dcs (rows 12..20) | pad], B = [x | 1]
+    //   du[h, col0 + j] = row h, j < J-1 ;   dc[h] = row 12+h, j == J-1
+    if (j < J - 1) { if (i < GEOBI_H) dst = o.C + (size_t)i * o.ldc + j; }
+    else if (o.C2 != nullptr && i >= GEOBI_HP && i < GEOBI_HP + GEOBI_H) dst = o.C2 + (i - GEOBI_HP);
+  }
+  if (dst != nullptr) *dst = o.accumulate ? *dst + s : s;
+}
+
 // Each wave owns a (32*TI) x (32*TJ) output tile and a slice of the reduction (node) range.
 // Operands are read straight from global memory in MFMA fragment order: for a k-step of two
 // consecutive nodes, lanes 0-31 read 32 consecutive floats of node m, lanes 32-63 of node m+1.
@@ -292,12 +334,18 @@ template <int TI, int TJ, int U, bool VA>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, int64_t M, int I,
                                                       int J, int ones_row, int ones_col, int tiles_j,
-                                                      int64_t m_per_slice, float* __restrict__ slabs) {
+                                                      int64_t m_per_slice, float* __restrict__ slabs, int sum_row) {
   // I, J are the LOGICAL output sizes; row `ones_row` of A^T / column `ones_col` of B read as 1
   // (bias-style column sums ride along in the same pass); pass -1 to disable.  They are always the
   // LAST logical row / column.
   // The 4 waves of a block own 4 consecutive node slices of the SAME output tile and fold their
   // accumulators through LDS, so one slab is written per block (4x fewer slabs to reduce).
+  // sum_row >= 0 (== I - 1): logical row I - 1 of the product is the COLUMN SUMS of B -- what an implicit ones row of
+  // A^T would give, but formed on the VALU from the B values the waves stream anyway (TJ adds per TI x TJ MFMAs; as
+  // an MFMA row it cost a whole padded 32-row tile).  Only the blocks of the first row tile form them.
+  // (Tried in round 3: the block that arrives LAST at its tile -- a ticket behind an agent-scope release -- adds the
+  // tile's slabs itself, no tn_reduce launch.  3 x slower: 5-20 tiles x 1 block then do the work of the I J / 64 blocks of
+  // tn_reduce_kernel, 150 us against 46 + 16 us per product.  profiles/r03_side_stream.txt)
   static_assert(!VA || TI == 4, "vector A loads feed 4 row tiles");
   __shared__ float red[2][TI * TJ * 16 * 64];
   const int lane = threadIdx.x & 63;
@@ -309,7 +357,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   int64_t m_end = m_begin + m_per_slice;
   if (m_end > M) m_end = M;
   const int i0 = ti * 32 * TI, j0 = tj * 32 * TJ;
-  const int Id = I - (ones_row >= 0 ? 1 : 0), Jd = J - (ones_col >= 0 ? 1 : 0);   // columns that exist in memory
+  const int Id = I - ((ones_row >= 0 || sum_row >= 0) ? 1 : 0), Jd = J - (ones_col >= 0 ? 1 : 0);   // columns that exist in memory
+  const bool do_sum = sum_row >= 0 && ti == 0;                    // block-uniform
+  float csum[TJ];
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) csum[b] = 0.f;
   const int half = lane >> 5, l31 = lane & 31;
 
   f32x16 acc[TI][TJ];
@@ -392,6 +444,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < TJ; ++b) y[b] = ok ? y[b] : 0.f;
       }
+      if (do_sum) {
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) csum[b] += y[b];
+      }
 #pragma unroll
       for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -439,21 +495,42 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) red[0][((a * TJ + b) * 16 + r) * 64 + lane] = acc[a][b][r];
   }
   __syncthreads();
-  if (wave != 0) return;
   float* out = slabs + (size_t)blockIdx.y * I * J;
+  if (wave == 0) {
 #pragma unroll
-  for (int a = 0; a < TI; ++a)
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) {
+        int jj = j0 + b * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r] + red[0][((a * TJ + b) * 16 + r) * 64 + lane];
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int ii = VA ? i0 + 4 * rr + a : i0 + a * 32 + rr;
+          if (jj < J && ii < Id + (ones_row >= 0 ? 1 : 0)) out[(size_t)ii * J + jj] = v;
+        }
+      }
+  }
+  // ---- column sums of B: the two nodes of a pair (lane halves), then the four waves in wave order
+  if (do_sum) {
+    __syncthreads();                                   // red[] is free again
 #pragma unroll
     for (int b = 0; b < TJ; ++b) {
-      int jj = j0 + b * 32 + l31;
+      const float t = csum[b] + __shfl_xor(csum[b], 32, 64);
+      if (half == 0) red[0][(wave * TJ + b) * 32 + l31] = t;
+    }
+    __syncthreads();
+    if (wave == 0 && half == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[a][b][r] + red[0][((a * TJ + b) * 16 + r) * 64 + lane];
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int ii = VA ? i0 + 4 * rr + a : i0 + a * 32 + rr;
-        if (jj < J && ii < I) out[(size_t)ii * J + jj] = v;
+      for (int b = 0; b < TJ; ++b) {
+        const int jj = j0 + b * 32 + l31;
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) t += red[0][(w4 * TJ + b) * 32 + l31];
+        if (jj < J) out[(size_t)sum_row * J + jj] = t;
       }
     }
+  }
 }
 
 // 64 outputs per block, four threads per output: thread (e, q) adds slabs q, q + 4, ... (independent loads, eight in
@@ -463,22 +540,30 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   int idx = blockIdx.x * 64 + e;
-  if (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr && blockIdx.x == gridDim.x - 1) {
-    // one extra block: bias.grad[c] = sum_h (ones row)[h Cout + c].  The 9 Cout ones-row sums are formed by all 256
-    // threads (one plain slab sum each, like every other output), then folded per channel in head order.
-    __shared__ float ones_sum[GEOBI_H * 128];
-    const int HCo = GEOBI_H * o.Cout;
-    const float* base = slabs + (size_t)(I - 1) * J;
-    for (int j = threadIdx.x; j < HCo; j += blockDim.x) {
+  const int nbias = (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr) ? (o.Cout + 7) / 8 : 0;
+  if (nbias > 0 && (int)blockIdx.x >= (int)gridDim.x - nbias) {
+    // extra blocks: bias.grad[c] = sum_h (sums row)[h Cout + c], eight channels per block.  72 (head, channel) sums,
+    // three threads each (slabs k = part, part + 3, ...: three chains of independent loads; one thread per sum walking
+    // every slab in ONE block for all channels made this the longest block of the launch), folded in the fixed order
+    // part 0..2, then heads 0..8 per channel.
+    __shared__ float psum[3][GEOBI_H * 8];
+    const int c0 = ((int)blockIdx.x - ((int)gridDim.x - nbias)) * 8;
+    const int pair = threadIdx.x / 3, part = threadIdx.x % 3;          // pair = h * 8 + cl
+    if (pair < GEOBI_H * 8) {
+      const int h = pair >> 3, c = c0 + (pair & 7);
       float t = 0.f;
+      if (c < o.Cout) {
+        const float* base = slabs + (size_t)(I - 1) * J + h * o.Cout + c;
 #pragma unroll 8
-      for (int k = 0; k < slices; ++k) t += base[(size_t)k * I * J + j];
-      ones_sum[j] = t;
+        for (int k = part; k < slices; k += 3) t += base[(size_t)k * I * J];
+      }
+      psum[part][pair] = t;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < o.Cout; c += blockDim.x) {
+    if (threadIdx.x < 8 && c0 + (int)threadIdx.x < o.Cout) {
+      const int c = c0 + threadIdx.x;
       float t = 0.f;
-      for (int h = 0; h < GEOBI_H; ++h) t += ones_sum[h * o.Cout + c];
+      for (int h = 0; h < GEOBI_H; ++h) t += (psum[0][h * 8 + threadIdx.x] + psum[1][h * 8 + threadIdx.x]) + psum[2][h * 8 + threadIdx.x];
       o.C2[c] = o.accumulate ? o.C2[c] + t : t;
     }
     return;
@@ -492,43 +577,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   __syncthreads();
   if (q != 0 || idx >= I * J) return;
   const float s = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
-  int i = idx / J, j = idx % J;
-  float* dst = nullptr;
-  if (o.mode == TN_PLAIN) {
-    // an implicit ones row / column (always the last one) lands in C2
-    if (o.extra_row && i == I - 1) { if (!(o.extra_col && j == J - 1)) dst = o.C2 + j; }
-    else if (o.extra_col && j == J - 1) dst = o.C2 + i;
-    else dst = o.C + (size_t)i * o.ldc + j;
-  } else if (o.mode == TN_LIN_UNPACK) {
-    // rows are (head h, in-channel k) of the packed weight, columns are out-channels:
-    // lin.weight[h * Cout + o, k]  (FeaStConv `lin.weight [H*Cout, Cin]`); the implicit ones row
-    // (i == I - 1) carries the bias gradient
-    if (i == I - 1) dst = o.C2 + j;
-    else {
-      int h = i / o.Cin, k = i % o.Cin;
-      if (h < GEOBI_H) dst = o.C + ((size_t)h * o.Cout + j) * o.Cin + k;
-    }
-  } else if (o.mode == TN_RPRIME) {
-    // rows: input channels (+ an implicit ones row when extra_row), columns: r' = [r (9 Cout) | dp 9 + 3 | dcs 9 + 3]
-    //   data row i, j < 9 Cout            -> lin.weight.grad[j, col0 + i]        (j = h Cout + o)
-    //   data row i, 9 Cout <= j < +9      -> u.weight.grad[j - 9 Cout, col0 + i]
-    //   ones row,   j in the dcs columns  -> c.grad[h]
-    //   ones row,   j < Cout              -> bias.grad[j] = sum_h (ones row)[h Cout + j]   (sum_h sum_j q_ijh / deg_i = 1)
-    const int HC = GEOBI_H * o.Cout;
-    const bool ones = o.extra_row && i == I - 1;
-    if (!ones) {
-      if (j < HC) dst = o.C + ((size_t)j * o.Cin + o.col0 + i);
-      else if (j < HC + GEOBI_H && o.C3 != nullptr) dst = o.C3 + ((size_t)(j - HC) * o.Cin + o.col0 + i);
-    } else if (j >= HC + GEOBI_HP && j < HC + GEOBI_HP + GEOBI_H) {
-      if (o.C4 != nullptr) dst = o.C4 + (j - HC - GEOBI_HP);
-    }          // bias.grad: the extra block above
-  } else {
-    // TN_DU_DC: A = [dp (rows 0..8) | pad | dcs (rows 12..20) | pad], B = [x | 1]
-    //   du[h, col0 + j] = row h, j < J-1 ;   dc[h] = row 12+h, j == J-1
-    if (j < J - 1) { if (i < GEOBI_H) dst = o.C + (size_t)i * o.ldc + j; }
-    else if (o.C2 != nullptr && i >= GEOBI_HP && i < GEOBI_HP + GEOBI_H) dst = o.C2 + (i - GEOBI_HP);
-  }
-  if (dst != nullptr) *dst = o.accumulate ? *dst + s : s;
+  tn_emit(o, idx / J, idx % J, I, J, s);
 }
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, int lda, int64_t M, int J,
@@ -707,7 +756,11 @@ size_t gemm_tn_ws_bytes(int I, int J, int64_t M) {
   TnPlan p0 = plan_tn(nullptr, 4, I, J, M, (I & 3) == 1 ? I - 1 : -1);
   TnPlan p1 = plan_tn(nullptr, 1, I, J, M, -1);
   int by = p0.blocks_y > p1.blocks_y ? p0.blocks_y : p1.blocks_y;
-  return align_up((size_t)by * I * J * sizeof(float)) + 256;
+  // the caller may ask for the column sums of B as one more row (I + 1 rows per slab) + a [J] scratch for them
+  TnPlan p2 = plan_tn(nullptr, 4, I > 1 ? I - 1 : I, J, M, -1), p3 = plan_tn(nullptr, 1, I > 1 ? I - 1 : I, J, M, -1);
+  if (p2.blocks_y > by) by = p2.blocks_y;
+  if (p3.blocks_y > by) by = p3.blocks_y;
+  return align_up((size_t)by * (I + 1) * J * sizeof(float)) + align_up((size_t)J * sizeof(float)) + 512;
 }
 
 // Upper bound over every column width J' <= J the caller may pass for the same (I, M): the conv backward
@@ -722,26 +775,25 @@ size_t gemm_tn_ws_bytes_any_width(int I, int J, int64_t M) {
 }
 
 int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, int J, int ones_row, int ones_col,
-            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s) {
+            const TnOutput& o, void* ws, size_t ws_bytes, hipStream_t s, int sum_row) {
   if (I <= 0 || J <= 0) return 0;
-  GEOBI_REQUIRE(M >= 0 && I - (ones_row >= 0) >= 1 && J - (ones_col >= 0) >= 1, "gemm_tn: empty operand");
+  const bool extra = ones_row >= 0 || sum_row >= 0;
+  GEOBI_REQUIRE(M >= 0 && I - extra >= 1 && J - (ones_col >= 0) >= 1, "gemm_tn: empty operand");
   GEOBI_REQUIRE(ones_row < 0 || ones_row == I - 1, "gemm_tn: the ones row is the last row");
+  GEOBI_REQUIRE(sum_row < 0 || (sum_row == I - 1 && ones_row < 0), "gemm_tn: the column-sums row is the last row");
   GEOBI_REQUIRE(ones_col < 0 || ones_col == J - 1, "gemm_tn: the ones column is the last column");
-  TnPlan p = plan_tn(A, lda, I, J, M, ones_row);
+  // the column-sums row is not an MFMA row: tiles cover the data rows only
+  const int I_mma = sum_row >= 0 ? I - 1 : I;
+  TnPlan p = plan_tn(A, lda, I_mma, J, M > 0 ? M : 1, ones_row);
   Arena a(ws, ws_bytes);
   float* slabs = a.take<float>((size_t)p.blocks_y * I * J);
   GEOBI_REQUIRE(a.ok() && slabs, "gemm_tn: workspace too small (%zu < %zu)", ws_bytes, a.off);
-  prof_begin(PROF_GEMM, s, 2.0 * (double)M * I * J, 2);
+  prof_begin(PROF_GEMM, s, 2.0 * (double)M * I_mma * J, 2);
   dim3 grid(p.tiles_i * p.tiles_j, p.blocks_y);
-  if (M == 0) {                                     // no nodes: the sums are zero
-    GEOBI_HIP(hipMemsetAsync(slabs, 0, (size_t)p.blocks_y * I * J * sizeof(float), s));
-    p.va = 9;                                       // no kernel below
-  }
 #define GEOBI_TN(TI_, TJ_, U_, VA_)                                                                         \
   gemm_tn_kernel<TI_, TJ_, U_, VA_><<<grid, 256, 0, s>>>(A, lda, B, ldb, M, I, J, ones_row, ones_col,         \
-                                                          p.tiles_j, p.m_per_slice, slabs)
+                                                          p.tiles_j, p.m_per_slice, slabs, sum_row)
   switch (p.va * 100 + p.ti * 10 + p.tj) {
-    case 900 ... 999: break;
     case 141: GEOBI_TN(4, 1, 4, true); break;
     case 11: GEOBI_TN(1, 1, 4, false); break;
     case 12: GEOBI_TN(1, 2, 4, false); break;
@@ -752,9 +804,8 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, int64_t M, int I, 
   }
 #undef GEOBI_TN
   GEOBI_LAUNCH_OK();
-  const int bias_block = (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr) ? 1 : 0;
-  GEOBI_REQUIRE(!bias_block || o.Cout <= 128, "gemm_tn: bias fold holds up to 128 output channels");
-  tn_reduce_kernel<<<cdiv((int64_t)I * J, 64) + bias_block, 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
+  const int bias_blocks = (o.mode == TN_RPRIME && o.extra_row && o.C2 != nullptr) ? cdiv(o.Cout, 8) : 0;
+  tn_reduce_kernel<<<cdiv((int64_t)I * J, 64) + bias_blocks, 256, 0, s>>>(slabs, p.blocks_y, I, J, o);
   GEOBI_LAUNCH_OK();
   prof_end(PROF_GEMM, s);
   return 0;

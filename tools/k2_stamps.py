@@ -23,10 +23,12 @@ buf = np.zeros((16384, 8), dtype=np.uint64)
 lib = _lib.lib()
 rc = lib.geobi_debug_stamps_bwd(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
 assert rc == 0
-nb = (N + 31) // 32
+rows = 16 if os.environ.get('GEOBI_TILE16', '1') != '0' else 32      # tile geometry of the build / switch
+nb = (N + rows - 1) // rows
 t = buf[:nb, :6].astype(np.int64)
 names = ['g tile + barrier', 'MFMA (wave 0)', 'barrier', 'row pass (wave 0)', 'group sums']
 d = np.diff(t, axis=1)
+print('%d-row tiles; ' % rows, end='')
 print('layer %d->%d backward, %d tiles; s_memtime ticks per phase, mean / median / p90' % (cin, cout, nb))
 for i, nme in enumerate(names):
     print('  %-28s %9.0f %9.0f %9.0f' % (nme, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
