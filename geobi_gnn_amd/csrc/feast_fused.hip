@@ -173,38 +173,16 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
 #else
     constexpr int UNR = VEC <= 4 ? 4 : 2;
 #endif
-    // Rows requested EARLY: a dependent global load costs ~3 k cycles here (stamps), and the chain of a chunk was
-    // rowptr -> col -> logits p[j] -> softmax -> (LDS) -> rows x[j].  The rows depend on col alone: lane t of a group
-    // holds the id of parked edge t, a DPP row broadcast hands it to all 16 channel lanes, and the first UNR rows are
-    // requested beside the logit rows, before the softmax.  (Per-edge-logit layers read the row itself for the logits:
-    // nothing to gain there.)
-#ifdef GEOBI_FUSED_EARLY
-    constexpr int EARLY = (LC == 0 && GEOBI_FUSED_EARLY) ? UNR : 0;
-#else
-    constexpr int EARLY = (LC == 0 && VEC <= 4) ? UNR : 0;       // 128-channel rows: 16 more live registers spill
-#endif
+    // (Tried in round 3: the first UNR rows requested right behind col -- lane t's id handed to the channel lanes by a
+    // DPP row broadcast -- i.e. beside the logit rows instead of behind the softmax: 48.3 against 47.9 us, neutral.)
     for (int base = rs; base < re; base += G) {
       // ---- lane k of the group handles edge base + k: logits, softmax, park q and the neighbour id
-      float xe[EARLY > 0 ? EARLY : 1][VEC];
       {
         const int e = base + k;
         float q[H];
         int j = ns;
-        if (e < re) j = col[e];
-        if constexpr (EARLY > 0) {
-          int je[EARLY];
-          static_for<0, EARLY>([&](auto ui) {
-            constexpr int u = decltype(ui)::value;
-            je[u] = __builtin_amdgcn_update_dpp(0, j, 0x150 + u, 0xf, 0xf, false);      // row_newbcast: lane u of the row
-          });
-          if (act) {
-#pragma unroll
-            for (int u = 0; u < EARLY; ++u)
-#pragma unroll
-              for (int q2 = 0; q2 < NP; ++q2) load_piece<PV>(fb[q2] + (size_t)je[u] * fs[q2], xe[u] + q2 * PV);
-          }
-        }
         if (e < re) {
+          j = col[e];
           float pc[H];
           if constexpr (LC == 0) {
             const float* prow = p + (size_t)ns * HP;
@@ -246,18 +224,11 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
         for (int t = 0; t < cnt; t += UNR) {
           // UNR neighbour rows in flight; the parked q of an edge is read (LDS broadcast) right before its FMAs
           float xv[UNR][VEC];
-          if (EARLY > 0 && t == 0) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
+          for (int u = 0; u < UNR; ++u) {
+            const int jn = __float_as_int(slot[t + u][H]);
 #pragma unroll
-              for (int v = 0; v < VEC; ++v) xv[u][v] = xe[EARLY > 0 ? u : 0][v];
-          } else {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-              const int jn = __float_as_int(slot[t + u][H]);
-#pragma unroll
-              for (int q = 0; q < NP; ++q) load_piece<PV>(fb[q] + (size_t)jn * fs[q], xv[u] + q * PV);
-            }
+            for (int q = 0; q < NP; ++q) load_piece<PV>(fb[q] + (size_t)jn * fs[q], xv[u] + q * PV);
           }
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
