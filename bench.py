@@ -98,7 +98,8 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
     lib.geobi_prof_enable(0)
     ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
     lc = best['cin'] if best['cin'] in (6, 12) else 0
-    kname = 'feast_fused_kernel<%d,0,%d,%d>' % (best['cin'], lc, best['cout'] // 32)     # <C, MODE, LC, NT>
+    rows = 32 if os.environ.get('GEOBI_TILE16', '1') == '0' else 16
+    kname = 'feast_fused_kernel<%d,0,%d,%d,%d>' % (best['cin'], lc, best['cout'] // 32, rows)   # <C, MODE, LC, NT, ROWS>
     avg_us = best['ms'] * 1e3 / best['launches']
     traffic, traffic_src = pmc_traffic(kname)
     # the same kernel against its other ceiling: the node transform on the fp32 matrix cores (2 N 9 Cin Cout flops per
@@ -137,7 +138,10 @@ def measure_mfma(net, bucket, opt, dv, df, steps=3):
         train_step(net, bucket, opt, dv, df, collective=False)
     torch.cuda.synchronize()
     out = {'bound': 'mfma', 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'pmc': 'profiles/r01_pmc_gemm_mfma.json (round-1 counters of these kernels: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32; tools/pmc_mfma.py)'}
+           'pmc': PMC_MFMA + ' (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32 of every kernel that runs a node '
+                  'transform, one rocprofv3 --pmc pass over this workload; tools/pmc_mfma.py): quoted below, the '
+                  'launch-bracketed figures of this run beside them',
+           'by_counters': pmc_mfma()}
     for name, tag in (('gemm_nn', 1), ('gemm_tn', 2)):
         n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         L.check(lib.geobi_prof_collect(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'prof_collect')
@@ -324,7 +328,8 @@ def log(msg):
     print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
-PMC_SUMMARY = 'profiles/r02_pmc_feast_fused.json'
+PMC_SUMMARY = 'profiles/r03_pmc_feast_fused.json'
+PMC_MFMA = 'profiles/r03_pmc_mfma.json'
 
 
 def pmc_traffic(kernel):
@@ -337,6 +342,18 @@ def pmc_traffic(kernel):
         return k['hbm_bytes_per_launch'], 'quoted from %s (tools/pmc_summary.py)' % PMC_SUMMARY
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def pmc_mfma():
+    """MFMA counters per kernel family, QUOTED from the committed pass (counters cannot be read in-process): achieved
+    TFLOP/s from SQ_INSTS_VALU_MFMA_MOPS_F32 over the dispatch time, fraction of the fp32 MFMA peak, MFMA-busy share."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, PMC_MFMA)))['kernels']
+    except (OSError, KeyError, ValueError):
+        return None
+    return {k.replace(' (all instantiations)', ''): {'tflops': v['tflops'], 'frac': v['frac_of_peak'],
+                                                      'mfma_busy': v['mfma_busy'], 'avg_us': v['avg_us']}
+            for k, v in ks.items() if k.endswith('(all instantiations)')}
 
 
 def cpu_baseline(freq=FREQ, timed=5, warm=2):

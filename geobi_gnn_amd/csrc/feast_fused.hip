@@ -610,6 +610,7 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
   // ---- row pass over the tile's nodes, lane = edge (feast_dev.h): the dz rows come from the LDS tile
   rowpass_edge_node<C, LC>(s_z + (wave * NPW + lane / G) * LDZ, xa, xb, Ca, p, cvec, s_u, rowptr, col, N,
                               tile * RT + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
+  GEOBI_STAMP_BWD(4);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

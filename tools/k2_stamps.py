@@ -25,13 +25,13 @@ rc = lib.geobi_debug_stamps_bwd(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_si
 assert rc == 0
 rows = 16 if os.environ.get('GEOBI_TILE16', '1') != '0' else 32      # tile geometry of the build / switch
 nb = (N + rows - 1) // rows
-t = buf[:nb, :6].astype(np.int64)
-names = ['g tile + barrier', 'MFMA (wave 0)', 'barrier', 'row pass (wave 0)', 'group sums']
+t = buf[:nb, :5].astype(np.int64)
+names = ['g tile + barrier', 'MFMA (wave 0)', 'barrier', 'row pass incl. sums (lane 0)']
 d = np.diff(t, axis=1)
 print('%d-row tiles; ' % rows, end='')
 print('layer %d->%d backward, %d tiles; s_memtime ticks per phase, mean / median / p90' % (cin, cout, nb))
 for i, nme in enumerate(names):
     print('  %-28s %9.0f %9.0f %9.0f' % (nme, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
-print('  %-28s %9.0f' % ('whole tile (wave 0)', (t[:, 5] - t[:, 0]).mean()))
-span = t[:, 5].max() - t[:, 0].min()
-print('  span first start -> last end: %d ticks; tiles in flight on average: %.1f' % (span, (t[:, 5] - t[:, 0]).sum() / span))
+print('  %-28s %9.0f' % ('whole tile (wave 0)', (t[:, 4] - t[:, 0]).mean()))
+span = t[:, 4].max() - t[:, 0].min()
+print('  span first start -> last end: %d ticks; tiles in flight on average: %.1f' % (span, (t[:, 4] - t[:, 0]).sum() / span))

@@ -5,9 +5,11 @@ rocprofv3 --pmc pass over the bench workload:
       --kernel-trace --output-format csv -d gpurun_out/pmc2/mfma -- \
       python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
   python tools/pmc_mfma.py gpurun_out/pmc2/mfma profiles/r01_pmc_gemm_mfma.json
+(round 3: the same pass also covers the fused FeaSt kernels, where the node transforms live since round 2:
+ feast_fused_kernel, feast_rowpass_fused_kernel, feast_rowpass_fused128_kernel -> profiles/r03_pmc_mfma.json)
 
 Per kernel (all launches of the run summed):
-  flops         = 512 * SQ_INSTS_VALU_MFMA_MOPS_F32   (one MOP = 512 flop; a 32x32x2 f32 MFMA is 8 MOPs)
+  flops         = 512 * SQ_INSTS_VALU_MFMA_MOPS_F32   (one MOP = 512 flop; a 32x32x2 f32 MFMA is 8 MOPs, a 16x16x4 one 4)
   mfma_busy     = SQ_VALU_MFMA_BUSY_CYCLES / (kernel ns * 2.4 GHz * 1024 SIMDs): fraction of the chip's MFMA issue
                   slots in use at the nominal clock (64 cycles per 32x32x2 f32 MFMA).  The gfx94x MfmaUtil formula
                   divides by GRBM_GUI_ACTIVE * CUs * 4 instead; on gfx950 GRBM_GUI_ACTIVE comes back summed over the
@@ -25,7 +27,8 @@ import re
 import sys
 
 PEAK_TFLOPS = 157.3
-DENSE = ('gemm_nn_kernel', 'gemm_tn_kernel', 'head_fwd_fused_kernel', 'head_bwd_fused_kernel', 'head_kernel')
+DENSE = ('gemm_nn_kernel', 'gemm_tn_kernel', 'head_fwd_fused_kernel', 'head_bwd_fused_kernel', 'head_kernel',
+         'feast_fused_kernel', 'feast_rowpass_fused_kernel', 'feast_rowpass_fused128_kernel')
 
 
 def short(name):
