@@ -105,6 +105,8 @@ __device__ unsigned long long g_stamps_bwd[16384][8];       // the fused backwar
 #define GEOBI_STAMP_BWD(i) do { } while (0)
 #endif
 
+// (Five waves per SIMD for the 32-channel instantiations -- 96 registers, LDS allows seven workgroups -- measured
+// 56.9 against 57.3 us for the dx kernel of the 64 -> 32 layers and slower elsewhere: not occupancy-bound.)
 template <int C, int MODE, int LC, int NT, int ROWS>
 __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,

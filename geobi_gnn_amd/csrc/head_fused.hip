@@ -34,17 +34,21 @@ __device__ __forceinline__ void load16(const float* __restrict__ p, float (&v)[1
 }
 
 // ------------------------------------------------------------------------------ forward
-// one wave = 32 nodes; no LDS, no barriers.
+// One block = 32 nodes, its four waves take every fourth hidden chunk of 32 units (8 chunks each) and their [32, NOUT]
+// partial outputs meet in 1.5 KB of LDS in wave order (fixed: deterministic).  Until round 3 one WAVE walked all 32
+// chunks of its 32 nodes: the vertex head of the bench batch was 320 blocks on 256 CUs -- one wave per SIMD, nothing to
+// run under a dependent MFMA chain (16 x 64 cycles per chunk, then ~100 VALU instructions that wait for it) and a second,
+// quarter-full round of blocks: 0.33 of the fp32 MFMA peak.
 template <int NOUT>
 __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
     const float* __restrict__ x, int N, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float slope, int mode,
     const float* __restrict__ dd, const float* __restrict__ resid, int ld_resid, float* __restrict__ raw,
     float* __restrict__ out) {
+  __shared__ float s_part[4][32][NOUT + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int n0 = (blockIdx.x * 4 + wave) * 32;
-  if (n0 >= N) return;
+  const int n0 = blockIdx.x * 32;
   const int row = min(n0 + l31, N - 1);
   float ax[16];
   load16(x + (size_t)row * CIN + 16 * half, ax);
@@ -74,15 +78,15 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
       for (int o = 0; o < NOUT; ++o) part[r][o] = fmaf(h, w2v[o], part[r][o]);
     }
   };
-  // the next chunk's W1 rows are in flight while the current chunk multiplies
+  // the next chunk's W1 rows are in flight while the current chunk multiplies; wave w owns chunks w, w + 4, ...
   const float* w1l = w1 + (size_t)l31 * CIN + 16 * half;
   float bwa[16], bwb[16];
-  load16(w1l, bwa);
-  for (int c = 0; c < NCHUNK; c += 2) {
-    load16(w1l + (size_t)(c + 1) * 32 * CIN, bwb);
+  load16(w1l + (size_t)wave * 32 * CIN, bwa);
+  for (int c = wave; c < NCHUNK; c += 8) {
+    load16(w1l + (size_t)(c + 4) * 32 * CIN, bwb);
     chunk(c, bwa);
-    if (c + 2 < NCHUNK) load16(w1l + (size_t)(c + 2) * 32 * CIN, bwa);
-    chunk(c + 1, bwb);
+    if (c + 8 < NCHUNK) load16(w1l + (size_t)(c + 8) * 32 * CIN, bwa);
+    chunk(c + 4, bwb);
   }
   // sum over the 32 hidden units held by the lanes of each half
 #pragma unroll
@@ -94,16 +98,23 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
       for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
       part[r][o] = v;
     }
-  // lane (l31 == r) finishes row(r, half)
+  // lane (l31 == r) holds row(r, half) of this wave's partial output
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (l31 != r) continue;
-    const int node = n0 + acc_row(r, half);
-    if (node >= N) continue;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) s_part[wave][acc_row(r, half)][o] = part[r][o];
+  }
+  __syncthreads();
+  // thread t < 32 finishes node n0 + t: the four waves' shares in wave order, bias, finish
+  if (threadIdx.x < 32) {
+    const int node = n0 + threadIdx.x;
+    if (node >= N) return;
     float v[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-      v[o] = part[r][o] + b2[o];
+      v[o] = ((s_part[0][threadIdx.x][o] + s_part[1][threadIdx.x][o]) + s_part[2][threadIdx.x][o]) +
+             s_part[3][threadIdx.x][o] + b2[o];
       raw[(size_t)node * NOUT + o] = v[o];
     }
     float res[3];
@@ -378,7 +389,7 @@ bool head_fused_supported(int Cin, int K, int nout) { return Cin == CIN && K == 
 int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
                    int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid, float* raw,
                    float* out, hipStream_t s) {
-  int blocks = cdiv(N, 128);
+  int blocks = cdiv(N, 32);
   if (nout == 3)
     head_fwd_fused_kernel<3><<<blocks, 256, 0, s>>>(x, (int)N, w1, b1, w2, b2, slope, mode, dd, resid, ld_resid, raw,
                                                     out);
