@@ -135,6 +135,13 @@ int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int
 int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream) {
   return expand_rowptr(rowptr, N, row, S(stream));
 }
+int geobi_concat32(const geobi_copy_seg_t* segs, int n_segs, int is_float, void* stream) {
+  if (n_segs <= 0) return 0;
+  NOTNULL(segs);
+  static_assert(sizeof(geobi_copy_seg_t) == sizeof(CopySeg) && offsetof(geobi_copy_seg_t, value) == offsetof(CopySeg, value),
+                "the internal and the public segment struct are one layout");
+  return concat32(reinterpret_cast<const CopySeg*>(segs), n_segs, is_float, S(stream));
+}
 int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream) {
   return gather_f32(src, idx, n, dst, S(stream));
 }

@@ -176,6 +176,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
               const float* gout, const float* p, const float* z, const float* wf_saved, float* dxa, float* dxb,
               float* dlin_w, float* du_w, float* dc, float* dbias, int accumulate, void* ws, size_t ws_bytes,
               hipStream_t s);
+struct CopySeg { const void* src; void* dst; int64_t n; int32_t add; float value; };     // = geobi_copy_seg_t
+int concat32(const CopySeg* segs, int n_segs, int is_float, hipStream_t s);
 // pool.hip
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
                     float* w_out, hipStream_t s, int32_t* zero8 = nullptr);

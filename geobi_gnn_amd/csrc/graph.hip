@@ -213,4 +213,64 @@ int csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t 
   return 0;
 }
 
+
+// ---------------------------------------------------------------- batched union copy (geobi_concat32)
+namespace {
+constexpr int kMaxSegs = 96;
+struct ConcatJob {
+  const uint32_t* src[kMaxSegs];
+  uint32_t* dst[kMaxSegs];
+  int64_t start[kMaxSegs + 1];     // element offsets of the jobs in the launch's index space
+  uint32_t fill[kMaxSegs];         // int32 add, or the bits of the float fill value
+  int n, is_float;
+};
+
+// One launch for every array of a union batch: 4 elements per thread and step; the job of an element is found by a
+// binary search over <= 96 start offsets held in LDS.
+__global__ __launch_bounds__(256) void concat32_kernel(ConcatJob job) {
+  __shared__ int64_t s_start[kMaxSegs + 1];
+  for (int i = threadIdx.x; i <= job.n; i += 256) s_start[i] = job.start[i];
+  __syncthreads();
+  const int64_t total = s_start[job.n];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = job.n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_start[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int64_t k = i - s_start[lo];
+    const uint32_t* src = job.src[lo];
+    uint32_t v = job.fill[lo];
+    if (src != nullptr) v = job.is_float ? src[k] : src[k] + v;
+    job.dst[lo][k] = v;
+  }
+}
+}  // namespace
+
+int concat32(const CopySeg* segs, int n_segs, int is_float, hipStream_t s) {
+  for (int base = 0; base < n_segs; base += kMaxSegs) {
+    ConcatJob job;
+    job.n = n_segs - base < kMaxSegs ? n_segs - base : kMaxSegs;
+    job.is_float = is_float;
+    job.start[0] = 0;
+    for (int i = 0; i < job.n; ++i) {
+      const CopySeg& g = segs[base + i];
+      GEOBI_REQUIRE(g.n >= 0 && (g.n == 0 || g.dst != nullptr), "concat32: bad segment %d", base + i);
+      job.src[i] = (const uint32_t*)g.src;
+      job.dst[i] = (uint32_t*)g.dst;
+      uint32_t bits;
+      if (is_float) memcpy(&bits, &g.value, 4); else bits = (uint32_t)g.add;
+      job.fill[i] = bits;
+      job.start[i + 1] = job.start[i] + g.n;
+    }
+    const int64_t total = job.start[job.n];
+    if (total == 0) continue;
+    int64_t blocks = (total + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    concat32_kernel<<<(int)blocks, 256, 0, s>>>(job);
+    GEOBI_LAUNCH_OK();
+  }
+  return 0;
+}
+
 }  // namespace geobi

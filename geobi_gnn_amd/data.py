@@ -6,6 +6,8 @@ The reference moves ``torch_geometric.data.Data`` objects through the network
 access, ``.to()``, ``num_nodes`` and ``hasattr`` semantics are needed on the path,
 so this is a plain attribute bag -- no PyG dependency.
 """
+import ctypes
+
 import torch
 
 
@@ -146,39 +148,127 @@ def union_batch(dual_list):
     return data_v, data_f
 
 
+class _CopySeg(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n', ctypes.c_int64), ('add', ctypes.c_int32),
+                ('value', ctypes.c_float)]
+
+
+class _Concat(object):
+    """Collects the copy jobs of a union batch (geobi_concat32): every int32 array in one launch, every fp32 array in
+    another, instead of a cat + add per array and mesh (~50 small launches and as many allocations per batch)."""
+
+    def __init__(self, device):
+        self.dev, self.jobs, self.keep = device, {0: [], 1: []}, []
+
+    def cat(self, parts, adds=None, tail=None, shape=None):
+        """parts: contiguous int32 / float32 tensors; adds: per-part int offsets (int32 only); tail: one closing int32."""
+        is_float = 1 if parts[0].dtype == torch.float32 else 0
+        total = sum(t.numel() for t in parts) + (1 if tail is not None else 0)
+        out = torch.empty(total, dtype=parts[0].dtype, device=self.dev)
+        off = 0
+        for k, t in enumerate(parts):
+            if not t.is_contiguous() or t.dtype != parts[0].dtype or t.device != self.dev:
+                raise ValueError('union batch: parts must be contiguous tensors of one dtype on %s' % self.dev)
+            self.keep.append(t)
+            self.jobs[is_float].append((t.data_ptr(), out.data_ptr() + 4 * off, t.numel(), 0 if adds is None else int(adds[k]), 0.0))
+            off += t.numel()
+        if tail is not None:
+            self.jobs[0].append((None, out.data_ptr() + 4 * off, 1, int(tail), 0.0))
+        return out if shape is None else out.view(shape)
+
+    def fill(self, sizes, values):
+        out = torch.empty(sum(sizes), dtype=torch.float32, device=self.dev)
+        off = 0
+        for n, v in zip(sizes, values):
+            self.jobs[1].append((None, out.data_ptr() + 4 * off, n, 0, float(v)))
+            off += n
+        return out
+
+    def run(self):
+        from . import _lib as L
+        for is_float in (0, 1):
+            jobs = self.jobs[is_float]
+            if jobs:
+                arr = (_CopySeg * len(jobs))(*[_CopySeg(*j) for j in jobs])
+                L.call('geobi_concat32', ctypes.cast(arr, ctypes.c_void_p), len(jobs), is_float, L.stream())
+        self.keep = None
+
+
 def union_batch_graphs(dual_list):
-    """``union_batch`` for device-resident pairs whose adjacency is already built (``Data.graph()``): the CSR
-    graphs are concatenated directly (``Graph.union``) -- no COO round trip, no sort, no host sync -- and edge
-    weights are taken in CSR order.  Same result fields as ``union_batch`` (``edge_index`` materialises
-    lazily, loop-free)."""
+    """``union_batch`` for device-resident pairs whose adjacency is already built (``Data.graph()``): the collate step
+    of a training loop (train_dual.py:199-201 hands the meshes over one by one; a batch is their disjoint union).  Every
+    array of the union -- row pointers, neighbour ids, weights, features, targets, face table, and, where every part
+    already has them, the reverse-edge index, the vertex -> corner lists and the per-mesh loss weights -- is an
+    offset-shifted concatenation of the parts' arrays: TWO launches (geobi_concat32: int32 arrays, fp32 arrays), no
+    sort, no host sync.  Same result fields as ``union_batch`` (``edge_index`` materialises lazily, loop-free)."""
     from .graph import Graph
+    from .network import mark_face_table, _CornerIndex
+    from . import ops
+    dev = dual_list[0][0].x.device
+    B = len(dual_list)
     gvs = [dv.graph() for dv, _ in dual_list]
     gfs = [df.graph() for _, df in dual_list]
-    ptr_v, ptr_f, fv = [0], [0], []
-    for dv, df in dual_list:
-        fv.append(df.fv_indices + ptr_v[-1])
-        ptr_v.append(ptr_v[-1] + dv.x.shape[0])
-        ptr_f.append(ptr_f[-1] + df.x.shape[0])
+    nv = [dv.x.shape[0] for dv, _ in dual_list]
+    nf = [df.x.shape[0] for _, df in dual_list]
+    off_v = [sum(nv[:k]) for k in range(B + 1)]
+    off_f = [sum(nf[:k]) for k in range(B + 1)]
+    cc = _Concat(dev)
 
-    def cat(items):
-        return torch.cat(items) if all(t is not None for t in items) else None
+    def graph_union(graphs, noff):
+        g = Graph(noff[-1], dev)
+        eoff = [sum(x.E for x in graphs[:k]) for k in range(B + 1)]
+        g.E = eoff[-1]
+        g.rowptr_out = cc.cat([x.rowptr_out[:x.N] for x in graphs], eoff[:-1], tail=eoff[-1])
+        g.col_out = cc.cat([x.col_out for x in graphs], noff[:-1]) if g.E else torch.empty(0, dtype=torch.int32, device=dev)
+        g.symmetric = all(x.symmetric for x in graphs) if all(x.symmetric is not None for x in graphs) else None
+        if g.symmetric and g.E and all(x.pos_in is not None for x in graphs):
+            # the parts' reverse-edge indices, shifted: the union needs no search of its own
+            g.rowptr_in, g.col_in = g.rowptr_out, g.col_out
+            g.pos_in = cc.cat([x.pos_in for x in graphs], eoff[:-1])
+        return g
 
-    data_v = Data(torch.cat([dv.x for dv, _ in dual_list]), None, y=cat([dv.y for dv, _ in dual_list]),
-                  depth_direction=cat([getattr(dv, 'depth_direction', None) for dv, _ in dual_list]), name='union-v')
-    data_f = Data(torch.cat([df.x for _, df in dual_list]), None, y=cat([df.y for _, df in dual_list]),
-                  fv_indices=torch.cat(fv), name='union-f')
-    data_v.set_graph(Graph.union(gvs))
-    data_f.set_graph(Graph.union(gfs))
+    def flt(items, cols=None):
+        if any(t is None for t in items):
+            return None
+        out = cc.cat([t.contiguous() for t in items])
+        return out if cols is None else out.view(-1, cols)
+
+    g_v, g_f = graph_union(gvs, off_v), graph_union(gfs, off_f)
+    data_v = Data(flt([dv.x for dv, _ in dual_list], dual_list[0][0].x.shape[1]), None,
+                  y=flt([dv.y for dv, _ in dual_list], 3),
+                  depth_direction=flt([getattr(dv, 'depth_direction', None) for dv, _ in dual_list], 3), name='union-v')
+    data_f = Data(flt([df.x for _, df in dual_list], dual_list[0][1].x.shape[1]), None,
+                  y=flt([df.y for _, df in dual_list], 3), name='union-f')
+    data_v.set_graph(g_v)
+    data_f.set_graph(g_f)
+    data_v.edge_weight = flt([g.weights_sorted(dv.edge_weight) for g, (dv, _) in zip(gvs, dual_list)])
+    data_f.edge_weight = flt([g.weights_sorted(df.edge_weight) for g, (_, df) in zip(gfs, dual_list)])
+    # face table: int32 form shifted by the vertex offsets; validated parts make a validated union (no range check)
     parts = [getattr(df.fv_indices, '_geobi_fv', None) for _, df in dual_list]
-    if all(p is not None and p[2] == dv.x.shape[0] for p, (dv, _) in zip(parts, dual_list)):
-        # every part's face table is already validated: so is the union (no range check = no host read later)
-        from .network import mark_face_table
-        fv32 = torch.cat([p[0] + off for p, off in zip(parts, ptr_v[:-1])])
-        mark_face_table(data_f.fv_indices, fv32, ptr_v[-1])
-    data_v.edge_weight = torch.cat([g.weights_sorted(dv.edge_weight) for g, (dv, _) in zip(gvs, dual_list)])
-    data_f.edge_weight = torch.cat([g.weights_sorted(df.edge_weight) for g, (_, df) in zip(gfs, dual_list)])
-    data_v.mesh_ptr = torch.tensor(ptr_v, dtype=torch.long)
-    data_f.mesh_ptr = torch.tensor(ptr_f, dtype=torch.long)
+    valid = all(p is not None and p[2] == n for p, n in zip(parts, nv))
+    fv32_parts = [p[0] if valid else df.fv_indices.to(torch.int32).contiguous() for p, (_, df) in zip(parts, dual_list)]
+    fv32 = cc.cat([t.view(-1) for t in fv32_parts], off_v[:-1]).view(-1, 3)
+    corner = None
+    if valid and all(p[1].index is not None for p in parts):
+        # vertex -> corner lists of the parts (a corner id is 3 * face + slot), shifted: no sort for the union
+        segptr = cc.cat([p[1].index.segptr[:n] for p, n in zip(parts, nv)], [3 * o for o in off_f[:-1]], tail=3 * off_f[-1])
+        members = cc.cat([p[1].index.members for p in parts], [3 * o for o in off_f[:-1]])
+        corner = (segptr, members)
+    # per-row loss weights 1 / (B n_mesh): what parallel.batched_losses would build from mesh_ptr
+    # (formed in fp32 exactly as parallel._mesh_weights forms them)
+    per_mesh = lambda counts: (1.0 / (torch.tensor(counts, dtype=torch.float32) * B)).tolist()
+    lw_v = cc.fill(nv, per_mesh(nv)) if B > 1 else None
+    lw_f = cc.fill(nf, per_mesh(nf)) if B > 1 else None
+    cc.run()
+    data_f.fv_indices = fv32.long()
+    if valid:
+        mark_face_table(data_f.fv_indices, fv32, off_v[-1])
+        if corner is not None:
+            data_f.fv_indices._geobi_fv[1].index = ops.SegmentIndex.view(fv32.view(-1), off_v[-1], corner[0], corner[1])
+    data_v.mesh_ptr = torch.tensor(off_v, dtype=torch.long)
+    data_f.mesh_ptr = torch.tensor(off_f, dtype=torch.long)
+    if B > 1:
+        data_v._loss_weights, data_f._loss_weights = lw_v, lw_f
     return data_v, data_f
 
 

@@ -62,6 +62,21 @@ int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int
                             int32_t* pos_rev, int32_t* flag, void* stream);
 int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream);
 int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream);
+/* geobi_concat32: the disjoint-union batch of several meshes (the data loader's collate step: code/train_dual.py:199-201
+ * hands the meshes over one by one; a batch is their union) as ONE launch per element type instead of a cat + add per
+ * array and mesh.  `segs` is a HOST array of n_segs copy jobs over 4-byte elements:
+ *   dst[i] = src[i] + add      (is_float == 0: int32 -- row pointers shifted by the edge offset, neighbour / vertex ids by
+ *                               the node offset, reverse-edge and corner positions by theirs)
+ *   dst[i] = src[i]            (is_float != 0: features, targets, weights; `add` ignored)
+ *   src == NULL: dst[i] = add  (int32) / value (float): closing row pointers, constant per-mesh loss weights.          */
+typedef struct {
+  const void* src;
+  void* dst;
+  int64_t n;
+  int32_t add;
+  float value;
+} geobi_copy_seg_t;
+int geobi_concat32(const geobi_copy_seg_t* segs, int n_segs, int is_float, void* stream);
 
 /* ---------------------------------------------------------------- FeaSt convolution --------
  * Replaces torch_geometric.nn.FeaStConv.forward / its autograd (16 call sites,

@@ -693,6 +693,58 @@ def test_union_of_prebuilt_graphs_equals_coo_union(dev):
     assert float(l0[0]) == float(l1[0]) and float(l0[1]) == float(l1[1])
 
 
+def test_union_of_prepared_meshes_carries_the_per_mesh_structures(dev):
+    """The collate step of a training loop (bench.py extra.fresh_batch): meshes pre-processed on the device once, with
+    their reverse-edge indices and vertex -> corner lists built once per mesh, are unioned by two geobi_concat32 launches.
+    Everything the union hands on must equal what the lazy builders give for the union itself -- reverse-edge index
+    (geobi_csr_reverse_index on the union), corner lists (radix sort of the union's 3 F corners), loss weights
+    (parallel._mesh_weights from mesh_ptr) -- and a training step on it must give the same loss and gradients as on a
+    union whose parts carried nothing."""
+    from geobi_gnn_amd import network, meshgen, meshprep, ops
+    from geobi_gnn_amd.data import union_batch_graphs
+    from geobi_gnn_amd.parallel import batched_losses, _mesh_weights
+    from geobi_gnn_amd.network import _fv_index
+
+    def parts(prepared):
+        out = []
+        for i, n in enumerate((7, 4, 9)):
+            noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed=60 + i)
+            dv, df = meshprep.build_dual_data(noisy, faces, clean, device=dev)
+            if prepared:
+                dv.graph().ensure_in(); df.graph().ensure_in()
+                _fv_index(df, dv.x.shape[0])[1].get()
+            out.append((dv, df))
+        return out
+    pv, pf = union_batch_graphs(parts(True))
+    qv, qf = union_batch_graphs(parts(False))
+    for a, b in ((pv, qv), (pf, qf)):
+        ga, gb = a.graph(), b.graph()
+        assert ga.pos_in is not None and gb.pos_in is None            # carried over / still to be built
+        gb.ensure_in()
+        assert torch.equal(ga.rowptr_out, gb.rowptr_out) and torch.equal(ga.col_out, gb.col_out)
+        assert torch.equal(ga.pos_in, gb.pos_in)
+        assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y) and torch.equal(a.edge_weight, b.edge_weight)
+        wa = a._loss_weights
+        del b._loss_weights
+        assert torch.equal(wa, _mesh_weights(b))
+    V = pv.x.shape[0]
+    ca, cb = _fv_index(pf, V)[1], _fv_index(qf, V)[1]
+    assert ca.index is not None and cb.index is None
+    ia, ib = ca.get(), cb.get()
+    assert torch.equal(pf.fv_indices, qf.fv_indices)
+    assert torch.equal(ia.segptr, ib.segptr) and torch.equal(ia.members, ib.members)
+    torch.manual_seed(2)
+    net = network.DualGNN().to(dev)
+    res = []
+    for dv, df in ((pv, pf), (qv, qf)):
+        net.zero_grad()
+        vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+        lv, ln = batched_losses(vp, npred, dv, df, 'L1', 'L1')
+        network.dual_loss(lv, ln).backward()
+        res.append((float(lv.detach()), float(ln.detach()), torch.cat([p.grad.flatten() for p in net.parameters()]).clone()))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize('pool_step,pool_type', [(1, 'max'), (3, 'max'), (3, 'mean')])
 def test_pooling_layer_other_step_counts_against_oracle(dev, pool_step, pool_type):
     """PoolingLayer with 1 and 3 matching steps (the network uses 2): HIP matching replayed on the oracle layer --
