@@ -47,10 +47,13 @@ def main(argv=None):
     train = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=1000 + i) for i in range(opt.n_train)]
     evals = [meshgen.synthetic_dual_data(opt.freq, sigmas[i % 3], seed=5000 + i) for i in range(opt.n_eval)]
     evals = [(a.to(device), b.to(device)) for a, b in evals]
-    # training meshes live on the device with their adjacency built once; a step's batch is a CSR concatenation
+    # training meshes live on the device with everything that depends on ONE mesh built once (adjacency, reverse-edge
+    # index, vertex -> corner lists); a step's batch is two concatenation launches (data.union_batch_graphs)
+    from geobi_gnn_amd.network import _fv_index
     train = [(a.to(device), b.to(device)) for a, b in train]
     for a, b in train:
-        a.graph(); b.graph()
+        a.graph().ensure_in(); b.graph().ensure_in()
+        _fv_index(b, a.x.shape[0])[1].get()
 
     net = network.DualGNN(force_depth=False, pool_type='max', wei_param=opt.wei_param).to(device)
     flat = FlatParameters(net)
