@@ -962,9 +962,10 @@ __global__ void pack_fused_batch_kernel(PackBatch pb) {
 
 // Tile geometry of the fused kernels: GEOBI_TILE16 (read once): 1 = 16-row tiles / four workgroups per CU (default),
 // 0 = 32-row tiles / two workgroups per CU.  Same-box A/B knob; both forms stay under the parity tests.
+int g_tile_rows = 0;          // 0: not set yet -> GEOBI_TILE16 decides; 16 / 32 once geobi_set_tile_rows was called
 bool tile16() {
-  static const bool on = [] { const char* f = getenv("GEOBI_TILE16"); return !f || atoi(f) != 0; }();
-  return on;
+  static const bool env_on = [] { const char* f = getenv("GEOBI_TILE16"); return !f || atoi(f) != 0; }();
+  return g_tile_rows ? g_tile_rows == 16 : env_on;
 }
 
 template <int C, int MODE, int LC, int NT, int ROWS>
@@ -1081,6 +1082,13 @@ int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const floa
   return 0;
 }
 }  // namespace
+
+// both tile geometries from one process (parity tests, A/B timing): rows = 16 / 32, 0 = back to GEOBI_TILE16
+int set_tile_rows(int rows) {
+  if (rows != 0 && rows != 16 && rows != 32) return set_error("tile rows: 16, 32 or 0 (environment default), got %d", rows);
+  g_tile_rows = rows;
+  return 0;
+}
 
 // split inputs: the row is read in batches of 16 channels (32 at 128 channels), so the first part must end on such a
 // boundary; 128 channels: Cout 64 or 128 (GEOBI_ROWPASS_FUSED128=0: the GEMM + standalone row pass)

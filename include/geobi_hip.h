@@ -119,6 +119,11 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Tile geometry of the fused FeaSt kernels: 16 (default: 16-node tiles on v_mfma_f32_16x16x4_f32, four workgroups per
+ * CU) or 32 (round-2 geometry: v_mfma_f32_32x32x2_f32, two per CU); 0 returns to the GEOBI_TILE16 environment default.
+ * Process-wide; for parity tests and same-process A/B timing.                                                       */
+int geobi_set_tile_rows(int rows);
+
 /* ---------------------------------------------------------------- pooling ------------------
  * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10
  *                         (code/net_util.py:226-230):  w_out = w_in + exp(-|x_row - x_col|^2 / 2)

@@ -104,17 +104,19 @@ def test_gemm_tn(dev, M, I, J):
 
 # ------------------------------------------------------------------------- FeaSt conv
 def _run_feast(dev, Cin, Cout, ei, n, slope, split, seed, xscale=1.0, x=None, fused=True):
-    """fused=True: the default path (aggregation + node transform in one kernel, feast_fused.hip);
+    """fused=True / 16: the default path (aggregation + node transform in one kernel on 16-node tiles, feast_fused.hip);
+    fused=32: the same kernels in the round-2 geometry (32-node tiles, geobi_set_tile_rows);
     fused=False: separate aggregation and GEMM kernels with z in HBM (GEOBI_FUSED=0)."""
-    from geobi_gnn_amd import ops
-    from geobi_gnn_amd.feast_conv import FeaStConv
-    from oracle import pyg_ops as P
+    from geobi_gnn_amd import ops, _lib as L
     was = ops.FUSED
     ops.FUSED = bool(fused)
     try:
+        if fused == 32:
+            L.call('geobi_set_tile_rows', 32)
         return _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x)
     finally:
         ops.FUSED = was
+        L.call('geobi_set_tile_rows', 0)
 
 
 def _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x):
@@ -151,7 +153,7 @@ def _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x):
     return errs
 
 
-@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('fused', [True, 32, False])
 @pytest.mark.parametrize('Cin,Cout,slope,split', [(6, 32, 0.2, False), (12, 32, 0.2, False), (32, 64, 0.2, False),
                                                   (64, 128, 0.2, False), (128, 128, 0.2, False),
                                                   (128, 64, 1.0, False), (128, 64, 0.2, True),

@@ -1213,3 +1213,30 @@ def test_executor_repairs_inside_pool_layer(dev, case):
         g = df.graph()
         deg = (g.rowptr_out[1:] - g.rowptr_out[:-1]).max().item()
         assert deg > 64
+
+
+def test_tile_geometries_agree_on_the_whole_network(dev):
+    """The fused FeaSt kernels in both tile geometries (16-node tiles on v_mfma_f32_16x16x4_f32, the default, and the
+    round-2 32-node tiles on v_mfma_f32_32x32x2_f32; geobi_set_tile_rows) through the whole training step: same packed
+    weights, different k order of the fp32 sums -- outputs within 1e-5, parameter gradients within the gradient bars."""
+    from geobi_gnn_amd import network, meshgen, _lib as L
+    from oracle import ref_model as R
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(R.DualGNN().state_dict(), 7)
+    dv, df = meshgen.synthetic_dual_data(12, 0.2, seed=12)
+    dv, df = dv.to(dev), df.to(dev)
+    res = {}
+    try:
+        for rows in (16, 32):
+            L.call('geobi_set_tile_rows', rows)
+            net = _hip_net(sd, dev)
+            vp, npred, loss, err_n = _step(net, network, dv.shallow_copy(), df.shallow_copy())
+            res[rows] = (vp.detach().clone(), npred.detach().clone(), loss,
+                         {k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        L.call('geobi_set_tile_rows', 0)
+    a, b = res[16], res[32]
+    assert rel_err(a[0], b[0]) < OUT_TOL and rel_err(a[1], b[1]) < OUT_TOL
+    assert abs(a[2] - b[2]) < 1e-5 * abs(b[2])
+    for k in a[3]:
+        assert rel_err(a[3][k], b[3][k]) < _grad_tol(k), k
