@@ -69,7 +69,12 @@ Fork fork_side_stream(hipStream_t main) {
   Fork f;
   if (!g_overlap) return f;
   if (g_side == nullptr) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return f; }
+    // lowest priority: the weight-gradient products fill what the backward's own kernels leave free instead of competing
+    // with them for workgroup slots (GEOBI_SIDE_PRIORITY=0: default priority, A/B knob)
+    int lo = 0, hi = 0;
+    static const bool low = [] { const char* e = getenv("GEOBI_SIDE_PRIORITY"); return !e || atoi(e) != 0; }();
+    if (!low || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) { g_side = nullptr; return f; }
     if (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming) != hipSuccess) { g_overlap = 0; return f; }
   }
