@@ -62,22 +62,36 @@ void prof_end(int kernel, hipStream_t s) {
 // ------------------------------------------------------------------------- side stream
 static int g_overlap = 1;
 static int g_defer = 0;     // 1: backward calls fork but do not join; the caller joins once (geobi_side_join)
-static hipStream_t g_side = nullptr;
+// Two side streams: [0] at the default priority, [1] at the lowest.  On a big batch the weight-gradient products
+// compete with the backward's own kernels for workgroup slots: at the lowest priority they fill what the main stream
+// leaves free (4.37-4.43 against 4.48-4.57 ms per step on the bench batch).  On small batches -- the host-bound regime,
+// the device has idle gaps anyway -- the low-priority queue is served late and the join at the end waits for it (n = 16:
+// 2.85-2.90 against 2.77-2.79 ms).  side_select() picks per backward; per-op callers get the default one.
+static hipStream_t g_sides[2] = {nullptr, nullptr};
+static int g_side_sel = 0;
+static hipStream_t g_side = nullptr;           // the stream the current / last fork used
 static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
+
+void side_select(int low_priority) {
+  static const bool allow = [] { const char* e = getenv("GEOBI_SIDE_PRIORITY"); return !e || atoi(e) != 0; }();
+  g_side_sel = (low_priority && allow) ? 1 : 0;
+}
 
 Fork fork_side_stream(hipStream_t main) {
   Fork f;
   if (!g_overlap) return f;
-  if (g_side == nullptr) {
-    // lowest priority: the weight-gradient products fill what the backward's own kernels leave free instead of competing
-    // with them for workgroup slots (GEOBI_SIDE_PRIORITY=0: default priority, A/B knob)
+  if (g_sides[g_side_sel] == nullptr) {
     int lo = 0, hi = 0;
-    static const bool low = [] { const char* e = getenv("GEOBI_SIDE_PRIORITY"); return !e || atoi(e) != 0; }();
-    if (!low || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) { g_side = nullptr; return f; }
-    if (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming) != hipSuccess) { g_overlap = 0; return f; }
+    if (g_side_sel == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&g_sides[g_side_sel], hipStreamNonBlocking, lo) != hipSuccess) {
+      g_sides[g_side_sel] = nullptr;
+      return f;
+    }
+    if (g_fork_ev == nullptr &&
+        (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming) != hipSuccess)) { g_overlap = 0; return f; }
   }
+  g_side = g_sides[g_side_sel];
   if (hipEventRecord(g_fork_ev, main) != hipSuccess) return f;
   if (hipStreamWaitEvent(g_side, g_fork_ev, 0) != hipSuccess) return f;
   f.side = g_side;

@@ -58,6 +58,7 @@ struct Fork {
   hipStream_t side = nullptr;   // nullptr: overlap disabled, run on the caller's stream
   hipEvent_t join = nullptr;
 };
+void side_select(int low_priority);            // which side stream the next forks use (default / lowest priority)
 Fork fork_side_stream(hipStream_t main);       // side stream waits for everything enqueued on `main` so far
 int join_side_stream(const Fork& f, hipStream_t main);   // `main` waits for the side stream
 int side_wait_main(const Fork& f, hipStream_t main);     // side stream waits for `main` as of now

@@ -595,12 +595,15 @@ extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const fl
   auto fail = [&](int rc) {
     (void)geobi_side_defer(0);
     (void)geobi_side_join(stream);
+    side_select(0);
     if (rc == kArenaFull) set_error("geobi_net_backward: arena too small (%zu bytes needed so far, %zu given)", b.peak, t->arena_bytes);
     return rc;
   };
   if (!b.ok) return fail(kArenaFull);
   if (zeros) GEOBI_HIP(hipMemsetAsync(zeros, 0, (size_t)(F > V ? F : V) * 3 * sizeof(float), s));
-  // weight-gradient GEMMs of every layer run on the side stream and are joined once, at the end
+  // weight-gradient GEMMs of every layer run on the side stream and are joined once, at the end; from ~80 k level-0 nodes
+  // on (device-bound batches) on the lowest-priority one
+  side_select(V + F >= 80000);
   (void)geobi_side_defer(1);
   int rc = head_bwd(t->feat_f, 32, F, P.fc_f1_w, P.fc_f1_b, 1024, P.fc_f2_w, 3, kLeak, 1, nullptr, nullptr, t->raw_f,
                     g_normals ? g_normals : zeros, g_feat_f, (float*)G.fc_f1_w, (float*)G.fc_f1_b, (float*)G.fc_f2_w,
@@ -624,5 +627,7 @@ extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const fl
   rc = gnn_backward(b, t->v, G.gnn_v, g_feat_v, nullptr, accumulate, s);
   if (rc) return fail(rc);
   (void)geobi_side_defer(0);
-  return geobi_side_join(stream);
+  rc = geobi_side_join(stream);
+  side_select(0);
+  return rc;
 }
