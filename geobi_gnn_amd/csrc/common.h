@@ -114,9 +114,9 @@ int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const flo
                     const int* rowptr, const int* col, int N, int LC, const float* ul, const float* Bp, int Cout,
                     const float* bias, float slope, float* out, hipStream_t s);
 int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, const int* rowptr_out,
-                   const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
-                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
-                   hipStream_t s);
+                   const int* col_out, const int* rowptr_in, const int* pos, const float* dl, const float* dpn, int N,
+                   int LC, const float* xl, const float* ul, const float* dpd, const float* Bp, int Cin, float* dxa,
+                   int Ca, float* dxb, int Cb, float* tile_out, hipStream_t s);
 bool feast_rowpass_fused_supported(int Cin, int Cb, int Cout);
 int set_tile_rows(int rows);
 int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,

@@ -894,9 +894,13 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     prof_end(PROF_ROWPASS, s);
     GEOBI_TRY(rc);
   }
-  // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx
-  feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, dpd, ld_dpd, 0);
-  GEOBI_LAUNCH_OK();
+  // 6. dp (tail columns of r'), and -- when the input needs a gradient -- r and dx.  The fused dx kernel sums dp
+  //    itself over the out-edges it walks anyway; a layer with per-edge logits and no input gradient (the first of each
+  //    branch) has no reader of dp at all (du / dc come from dl and dcs)
+  if (!rform && (dxa != nullptr || LC == 0)) {
+    feast_dp_gather_kernel<<<cdiv(N * 3, 256), 256, 0, s>>>(rowptr_out, pos_in, b.dl, b.dpn, (int)N, dpd, ld_dpd, 0);
+    GEOBI_LAUNCH_OK();
+  }
   // 7. du = dp^T x and dc = dcs^T 1 in one pass: A = r' tail [dp | dcs], B = [x | 1]; needs the row
   //    pass and dp_gather only -> also off the critical path (side stream, after an event on main)
   if (LC > 0) {
@@ -933,8 +937,8 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
       GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, Cin, Cout, b.bdx, s));
     }
     prof_begin(PROF_AGG_BWD, s, feast_fused_bytes(N, Ecap, Cout, Cin), Cout);
-    rc = feast_fused_dx(g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, (int)N, LC, xa, u_w, dpd, bdx, Cin, dxa,
-                        Cb ? Ca : Cin, dxb, Cb, b.rp, s);
+    rc = feast_fused_dx(g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, pos_in, b.dl, b.dpn, (int)N, LC, xa, u_w, dpd,
+                        bdx, Cin, dxa, Cb ? Ca : Cin, dxb, Cb, b.rp, s);
     prof_end(PROF_AGG_BWD, s);
     GEOBI_TRY(rc);
     // every weight gradient of the layer: [x | 1]^T r' (side stream; du / dc of the per-edge-logit layers come from

@@ -82,13 +82,17 @@ struct Shape {
   static constexpr int RED_FLOATS = ROWS == 32 ? NW * 32 * RED_LD : 4 * 16 * 36;     // K-split partial tiles
   static constexpr int TILE_FLOATS = ROWS * LD > RED_FLOATS ? ROWS * LD : RED_FLOATS;
   static constexpr int SLOT_FLOATS = SLOT_IN_ROW ? 0 : NWV * 64 * HP;
+  // MODE 1: the node's [dp | dcs] columns are formed while its edges are walked -- in their place at the end of the
+  // tile row when the row is one chunk, in a side array when the last chunk's columns overlap the parking slots
+  static constexpr int DP_FLOATS = (MODE == 1 && NCHUNK > 1) ? ROWS * 2 * HP : 0;
   static_assert(VEC * ACTIVE == C || C < 16, "channel split");
   static_assert(KD % KB == 0 && (NCHUNK == 1 || KC_FULL % KB == 0) && KC_LAST % KB == 0 && KC_LAST > 0, "whole k-blocks per chunk");
   static_assert(KC_MAX % 16 == 0 || ROWS == 32, "LD / 4 odd");
 };
 template <int C, int MODE, int LC, int ROWS>
 constexpr int fused_lds_floats() {
-  return Shape<C, MODE, ROWS>::TILE_FLOATS + Shape<C, MODE, ROWS>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0);
+  return Shape<C, MODE, ROWS>::TILE_FLOATS + Shape<C, MODE, ROWS>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0) +
+         Shape<C, MODE, ROWS>::DP_FLOATS;
 }
 // K of the PACKED weights (both geometries read the same pack): the r' / z row rounded up to 16
 constexpr int fused_k(int C, int MODE) { return ((MODE == 0 ? H * C : H * C + 2 * HP) + KPAD - 1) / KPAD * KPAD; }
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
     const int* __restrict__ deg_rowptr, int N, const float* __restrict__ xl, const float* __restrict__ ul,
-    const float* __restrict__ dpd, const float* __restrict__ Bp, int NOUT, const float* __restrict__ bias,
+    const float* __restrict__ dpd, const float* __restrict__ dl, const int* __restrict__ pos,
+    const float* __restrict__ dpn, const float* __restrict__ Bp, int NOUT, const float* __restrict__ bias,
     float slope, float* __restrict__ out, int ldo, float* __restrict__ out1, int split, int ldo1,
     float* __restrict__ tile_out) {
   using S = Shape<C, MODE, ROWS>;
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_slots = smem + S::TILE_FLOATS;
   float* s_u = s_slots + S::SLOT_FLOATS;
+  float* s_dp = s_u + (LC > 0 ? LC * HP : 0);
   if constexpr (LC > 0) stage_u<LC>(ul, s_u);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -159,6 +165,25 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     // row-gather loop: that is what lets four neighbour rows be in flight at once within the 128-register budget
     float xc[LC > 0 ? LC : 1];
     if constexpr (LC > 0) load_row<LC>(xl + (size_t)ns * LC, xc);
+    // MODE 1: dp_j = sum over the out-edges (j -> i) of dl_ij - dpn_j is summed right here, over the edges this phase
+    // walks anyway (dl row = one more 48-B read per edge next to the logit row; until round 3 a kernel of its own per
+    // layer): lane k < 3 owns float4 k of dp, lanes 3..5 fetch dcs
+    float* dprow = nullptr;
+    if constexpr (MODE == 1) {
+      dprow = NCHUNK == 1 ? zrow + H * C : s_dp + nl * (2 * HP);
+      if (k < 6) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+          if (k < 3) {
+            t = reinterpret_cast<const float4*>(dpn + (size_t)node * HP)[k];
+            t = make_float4(-t.x, -t.y, -t.z, -t.w);
+          } else {
+            t = reinterpret_cast<const float4*>(dpd + (size_t)node * (2 * HP))[k];
+          }
+        }
+        reinterpret_cast<float4*>(dprow)[k] = t;
+      }
+    }
     {
       float xs[VEC];
 #pragma unroll
@@ -183,8 +208,14 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
         const int e = base + k;
         float q[H];
         int j = ns;
+        float dsum[MODE == 1 ? H : 1];
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) dsum[h] = 0.f;
+        }
         if (e < re) {
           j = col[e];
+          if constexpr (MODE == 1) load_hp(dl + (size_t)pos[e] * HP, dsum);
           float pc[H];
           if constexpr (LC == 0) {
             const float* prow = p + (size_t)ns * HP;
@@ -217,6 +248,19 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
         dst[0] = make_float4(q[0], q[1], q[2], q[3]);
         dst[1] = make_float4(q[4], q[5], q[6], q[7]);
         dst[2] = make_float4(q[8], __int_as_float(j), 0.f, 0.f);
+        if constexpr (MODE == 1) {
+          // the group's 16 dl rows -> every lane holds the nine sums (fixed butterfly order); lane k < 3 adds its float4
+#pragma unroll
+          for (int h = 0; h < H; ++h) dsum[h] = group_allreduce<G>(dsum[h]);
+          if (k < 3) {
+            float4 t = reinterpret_cast<float4*>(dprow)[k];
+            const float4 a = k == 0 ? make_float4(dsum[0], dsum[1], dsum[2], dsum[3])
+                           : k == 1 ? make_float4(dsum[4], dsum[5], dsum[6], dsum[7])
+                                    : make_float4(dsum[8], 0.f, 0.f, 0.f);
+            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+            reinterpret_cast<float4*>(dprow)[k] = t;
+          }
+        }
       }
       wave_lds_sync();
       GEOBI_STAMP(1);
@@ -288,10 +332,9 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
       if constexpr (MODE == 0) {
         for (int i = nheads * C + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding
       } else {
-        if (k < 6) {                                                                // [dp | dcs]: 24 floats
-          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (valid) t = reinterpret_cast<const float4*>(dpd + (size_t)node * (2 * HP))[k];
-          reinterpret_cast<float4*>(zrow + nheads * C)[k] = t;
+        if constexpr (NCHUNK > 1) {                                                 // [dp | dcs]: 24 floats
+          if (k < 6)
+            reinterpret_cast<float4*>(zrow + nheads * C)[k] = reinterpret_cast<const float4*>(s_dp + nl * (2 * HP))[k];
         }
         for (int i = S::KR_LAST + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding behind them
       }
@@ -971,7 +1014,7 @@ bool tile16() {
 template <int C, int MODE, int LC, int NT, int ROWS>
 int launch_one(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
-               const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
+               const float* dl, const int* pos, const float* dpn, const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
                int ldo1, float* tile_out, hipStream_t s) {
   constexpr size_t lds = (size_t)fused_lds_floats<C, MODE, LC, ROWS>() * sizeof(float);
   static_assert(lds <= 163840, "tile exceeds the LDS of a CU");
@@ -983,20 +1026,20 @@ int launch_one(const float* xa, const float* xb, int Ca, const float* p, const f
     attr_set = true;
   }
   feast_fused_kernel<C, MODE, LC, NT, ROWS><<<xcd_grid(cdiv(N, ROWS)), 16 * ROWS, lds, s>>>(
-      xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1,
-      tile_out);
+      xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, dl, pos, dpn, Bp, NOUT, bias, slope, out, ldo, out1,
+      split, ldo1, tile_out);
   GEOBI_LAUNCH_OK();
   return 0;
 }
 
 #define GEOBI_FUSED_ARGS                                                                                            \
-  xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, Bp, NOUT, bias, slope, out, ldo, out1, split, ldo1, \
-      tile_out, s
+  xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, dl, pos, dpn, Bp, NOUT, bias, slope, out, ldo, out1, \
+      split, ldo1, tile_out, s
 
 template <int C, int MODE, int LC>
 int launch_nt(int NT, const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
               const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
-              const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
+              const float* dl, const int* pos, const float* dpn, const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
               int ldo1, float* tile_out, hipStream_t s) {
   // dx with per-edge logits writes a 6- or 12-channel input gradient: one column tile
   constexpr bool kNarrowOnly = MODE == 1 && LC > 0;
@@ -1195,7 +1238,8 @@ int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const flo
                     const float* bias, float slope, float* out, hipStream_t s) {
   const int* deg_rowptr = nullptr;
   const float* xl = xa;
-  const float* dpd = nullptr;
+  const float *dpd = nullptr, *dl = nullptr, *dpn = nullptr;
+  const int* pos = nullptr;
   const int NOUT = Cout, ldo = Cout, split = 0, ldo1 = 0;
   float* out1 = nullptr;
   float* tile_out = nullptr;
@@ -1212,10 +1256,12 @@ int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const flo
   }
 }
 
-// backward: (dxa | dxb) = [r | dp | dcs] W', r aggregated over the transposed CSR from g [N, Cout]
+// backward: (dxa | dxb) = [r | dp | dcs] W', r aggregated over the transposed CSR from g [N, Cout]; dp is formed in
+// the kernel from the row pass's dl [E, 12] (in-CSR order, reached through pos_in) and dpn [N, 12], dcs is the second
+// half of dpd's rows (the first half is not read)
 int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, const int* rowptr_out,
-                   const int* col_out, const int* rowptr_in, int N, int LC, const float* xl, const float* ul,
-                   const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
+                   const int* col_out, const int* rowptr_in, const int* pos, const float* dl, const float* dpn, int N,
+                   int LC, const float* xl, const float* ul, const float* dpd, const float* Bp, int Cin, float* dxa, int Ca, float* dxb, int Cb, float* tile_out,
                    hipStream_t s) {
   const float *xa = g, *xb = g;
   const int* rowptr = rowptr_out;
