@@ -342,6 +342,138 @@ __device__ __forceinline__ void rowpass_edge_node(
   bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same row pass with the neighbour rows STAGED through LDS (64-channel inputs, node-level logits).  In the form
+// above a lane reads its neighbour's row as sixteen private 16-B pieces, four in flight: every load instruction of a
+// wave touches 64 different cache lines (one per lane, an eighth of each used) and a chunk of items costs four
+// dependent L2 round trips.  Here the row arrives the way the forward kernel reads it -- half a row (32 channels =
+// one 128-B line) by eight adjacent lanes -- but lands in LDS, not in registers: `global_load_lds_dwordx4`, eight
+// instructions per half for the wave's 4 nodes x 16 items, all in flight at once at no register cost.  Landing zone =
+// the wave's own four dz rows (dead once their pieces sit in registers): instruction i covers items 2 i and 2 i + 1
+// and writes its 1 KiB lane-linearly (node g -> +256 B, odd item -> +128 B) at i x 1040 B -- the 16-B skew makes the
+// lane = item reads (ds_read_b128, lane k at (k >> 1) x 1040 + (k & 1) x 128) conflict-free.  Lane k of a group then
+// runs the same FMAs in the same order as above (channels ascending): the results are bit-identical.
+// Per chunk of 16 items: two staged halves = two round trips instead of four, an eighth of the cache-line lookups.
+template <int L>
+__device__ __forceinline__ int row_bcast(int v) {             // lane L of every 16-lane row -> the whole row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xf, 0xf, false);   // row_newbcast:L
+}
+
+template <int C, int LDZ>
+__device__ __forceinline__ void rowpass_edge_node_staged(
+    float* wave_rows, const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
+    const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N, int node, int g,
+    int k, float* __restrict__ dl, float* __restrict__ dpn, float* __restrict__ dcs, int ld_dcs) {
+  constexpr int G = 16, HALF = 32, HQ = HALF / 4;             // 16 pieces per head (= G), 8 per half row
+  constexpr int SLOT = 260;                                   // floats between two staging instructions (1 KiB + 16 B)
+  static_assert(C == 64, "a row is two 128-B halves");
+  static_assert(8 * SLOT <= 4 * LDZ, "the landing zone fits the wave's four dz rows");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const bool valid = node < N;
+  const int ns = valid ? node : N - 1;
+  const int rs = rowptr[ns];
+  const int deg = valid ? rowptr[ns + 1] - rs : -1;
+  const int Cb = C - Ca;
+
+  float dzr[H][4];                                            // piece (head h, 16-B piece k) of the node's dz row
+  const float* zrow = wave_rows + g * LDZ;
+#pragma unroll
+  for (int h = 0; h < H; ++h) load_piece<4>(zrow + h * C + k * 4, dzr[h]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane's pieces have arrived: the rows may be overwritten
+
+  float cc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) cc[h] = cvec[h];
+  const float invd = 1.0f / (float)(deg + 1);
+  float dsum[H], d[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { dsum[h] = 0.f; d[h] = 0.f; }
+  bool self = false;
+  const float* my = wave_rows + (k >> 1) * SLOT + g * 64 + (k & 1) * HALF;
+
+  for (int base = 0; base <= deg; base += G) {
+    const int idx = base + k;
+    const bool real = idx < deg;
+    self = idx == deg;
+    const int e = rs + idx;
+    const int j = real ? col[e] : ns;                          // lanes past the node's items work on its own row
+    auto stage = [&](auto halfc) {
+      constexpr int half = decltype(halfc)::value;
+      const float* rbase = half * HALF < Ca ? xa + half * HALF : xb + (half * HALF - Ca);
+      const int rstride = half * HALF < Ca ? Ca : Cb;
+      static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const int jlo = row_bcast<2 * i>(j), jhi = row_bcast<2 * i + 1>(j);
+        const int jj = (k & 8) ? jhi : jlo;
+        __builtin_amdgcn_global_load_lds(rbase + (size_t)jj * rstride + 4 * (k & 7), (lds_ptr)(wave_rows + i * SLOT), 16, 0,
+                                         0);
+      });
+    };
+    stage(std::integral_constant<int, 0>{});
+    float q[H];
+    if (real) {
+      float pc[H], pn[H];
+      load_hp(p + (size_t)ns * HP, pc);
+      load_hp(p + (size_t)j * HP, pn);
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = pn[h] - pc[h] + cc[h];
+    } else {                                                   // the self loop: u (x_i - x_i) + c = c exactly
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = cc[h];
+    }
+    softmax9(q);
+    float sv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) sv[h] = 0.f;
+    static_for<0, 2>([&](auto halfc) {
+      constexpr int half = decltype(halfc)::value;
+      if constexpr (half == 1) stage(halfc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the half rows have landed
+      static_for<0, HQ / 4>([&](auto bi) {
+        constexpr int q0 = decltype(bi)::value * 4;
+        float xj[4][4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) load_piece<4>(my + (q0 + qd) * 4, xj[qd]);
+        static_for<0, 4>([&](auto qi) {
+          constexpr int qd = decltype(qi)::value;
+          static_for<0, H>([&](auto hi) {
+            constexpr int h = decltype(hi)::value;
+            fmac_bcast<half * HQ + q0 + qd, 4>(sv[h], dzr[h], xj[qd]);
+          });
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and have been read: the zone may be refilled
+    });
+    float tq = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) tq = fmaf(q[h], sv[h], tq);
+#pragma unroll
+    for (int h = 0; h < H; ++h) d[h] = q[h] * (sv[h] - tq) * invd;
+    if (real) {
+      float4* drow = reinterpret_cast<float4*>(dl + (size_t)e * HP);
+      drow[0] = make_float4(d[0], d[1], d[2], d[3]);
+      drow[1] = make_float4(d[4], d[5], d[6], d[7]);
+      drow[2] = make_float4(d[8], 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; ++h) dsum[h] += d[h];
+    }
+  }
+  float dself[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dsum[h] = group_allreduce<G>(dsum[h]);
+    dself[h] = group_allreduce<G>(self ? d[h] : 0.f);
+  }
+  if (!valid || k != 0) return;
+  float4* a = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
+  a[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
+  a[1] = make_float4(dsum[4], dsum[5], dsum[6], dsum[7]);
+  a[2] = make_float4(dsum[8], 0.f, 0.f, 0.f);
+  float4* bq = reinterpret_cast<float4*>(dcs + (size_t)node * ld_dcs);
+  bq[0] = make_float4(dsum[0] + dself[0], dsum[1] + dself[1], dsum[2] + dself[2], dsum[3] + dself[3]);
+  bq[1] = make_float4(dsum[4] + dself[4], dsum[5] + dself[5], dsum[6] + dself[6], dsum[7] + dself[7]);
+  bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
+}
 
 }  // namespace feast_dev
 }  // namespace geobi

@@ -480,7 +480,9 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
 // gains: 262 against 265 M-edges/s in a same-box A/B (tools/ab_lib.sh).  32 is the product build.
 // (Round 2 tried 16 rows on HALF-USED 32 x 32 MFMA tiles: twice the matrix work per node, no gain.  The 16-row form below
 // runs on v_mfma_f32_16x16x4_f32: same matrix work per node as the 32-row form.)
-template <int C, int LC, int COUT, int RT>
+// RP = 1: the row pass stages the neighbour rows through LDS (feast_dev.h: rowpass_edge_node_staged; 64 channels, node-level
+// logits, both input parts whole 32-channel halves).
+template <int C, int LC, int COUT, int RT, int RP = 0>
 __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
   GEOBI_STAMP_BWD(0);
 
   // ---- g tile: gradient through the fused leaky-relu, kept for the MFMAs and written out for the dx kernel
-  {
+  auto g_tile = [&]() {
     constexpr int Q = COUT / 4;
     for (int i = threadIdx.x; i < RT * Q; i += KT) {
       const int r = i / Q, c4 = (i - r * Q) * 4;
@@ -523,14 +525,15 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
       }
       *reinterpret_cast<float4*>(s_g + r * GL + c4) = v;
     }
-  }
-  __syncthreads();
-  GEOBI_STAMP_BWD(1);
+    __syncthreads();
+    GEOBI_STAMP_BWD(1);
+  };
 
   // ---- matrix phase: dz[RT, K] = g[RT, COUT] Wf^T; wave w owns column tiles w, w + KW, w + 2 KW, ...
   if constexpr (RT == 32) {
     // The weights of up to three of a wave's tiles are requested together, four k-blocks at a time: one exposed load
     // latency per batch instead of one per tile.
+    g_tile();
     const int hf = lane >> 5, l31 = lane & 31;
     constexpr int NKB = COUT / 8;
     constexpr int MAXT = (NCT + KW - 1) / KW;                      // column tiles per wave
@@ -582,69 +585,66 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
   } else {
     // 16 rows: 16-column tiles on v_mfma_f32_16x16x4_f32, lane = (row / column l15, k-slot kq); a lane's 16-B load of
     // Wf row (ct 16 + l15) at k = 16 kb + 4 kq feeds four MFMAs, the matching A operand is the g tile's
-    // [l15][16 kb + 4 kq ..].  A wave's tiles are independent accumulator chains (TB per round, their MFMAs interleaved:
-    // dependent latency 40 cycles against a 32-cycle issue interval).
+    // [l15][16 kb + 4 kq ..].  A wave's tiles are independent accumulator chains (all of them in one round, their MFMAs
+    // interleaved: dependent latency 40 cycles against a 32-cycle issue interval).
+    // The weights depend on nothing the tile computes: the first TWO batches are requested at the very top of the
+    // kernel, ahead of the g tile (a Cout = 32 layer's whole 72 KB), so their L2 round trip -- 3-5 k cycles with three
+    // other workgroups' row gathers queued on the CU's memory pipeline -- runs under the g tile's own loads and barrier
+    // instead of in front of the first MFMA; every further batch is requested two batches ahead into the registers the
+    // batch just issued has freed.
     const int kq = lane >> 4, l15 = lane & 15;
     constexpr int NCT16 = (K + 15) / 16;
     constexpr int NKB = COUT / 16;                                 // 16-deep k-blocks
-    constexpr int MAXT = (NCT16 + KW - 1) / KW;                    // column tiles per wave
-    constexpr int TB = MAXT <= 9 ? MAXT : 5;                       // tiles per round (all of them up to 64 channels)
+    constexpr int TB = (NCT16 + KW - 1) / KW;                      // column tiles per wave: one round
     constexpr int HB = TB > 5 ? 1 : (NKB < 2 ? NKB : 2);           // k-blocks per batch of weight loads
     constexpr int NB = NKB / HB;
+    static_assert(TB <= 9, "accumulators of all of a wave's tiles at once");
     static_assert(NKB % HB == 0, "whole batches");
-    const float* arow = s_g + l15 * GL + 4 * kq;
+    const float* brow[TB];
 #pragma unroll
-    for (int t0 = 0; t0 < MAXT; t0 += TB) {
-      const float* brow[TB];
-      f32x4 acc[TB];
-#pragma unroll
-      for (int t = 0; t < TB; ++t) {
-        const int ct = wave + (t0 + t) * KW;
-        const int krow = min(ct * 16 + l15, Kp - 1);               // rows past K: clamped, their columns are never read
-        brow[t] = Wf + (size_t)krow * COUT + 4 * kq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
-      }
-      // the next batch's weights are requested before the current batch's MFMAs (36 x 32 cycles cover an L2 round trip)
-      float4 w[TB][HB], wn[TB][HB];
+    for (int t = 0; t < TB; ++t) {
+      const int ct = wave + t * KW;
+      const int krow = min(ct * 16 + l15, Kp - 1);                 // rows past K: clamped, their columns are never read
+      brow[t] = Wf + (size_t)krow * COUT + 4 * kq;
+    }
+    float4 w[2][TB][HB];
+    auto load_batch = [&](int b) {
 #pragma unroll
       for (int t = 0; t < TB; ++t)
 #pragma unroll
-        for (int u = 0; u < HB; ++u) w[t][u] = *reinterpret_cast<const float4*>(brow[t] + 16 * u);
+        for (int u = 0; u < HB; ++u) w[b & 1][t][u] = *reinterpret_cast<const float4*>(brow[t] + 16 * (b * HB + u));
+    };
+    load_batch(0);
+    if constexpr (NB > 1) load_batch(1);
+    g_tile();
+    const float* arow = s_g + l15 * GL + 4 * kq;
+    f32x4 acc[TB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (b + 1 < NB) {
+    for (int t = 0; t < TB; ++t)
 #pragma unroll
-          for (int t = 0; t < TB; ++t)
+      for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < HB; ++u) wn[t][u] = *reinterpret_cast<const float4*>(brow[t] + 16 * ((b + 1) * HB + u));
-        }
+    for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int u = 0; u < HB; ++u) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (b * HB + u));
+      for (int u = 0; u < HB; ++u) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (b * HB + u));
 #pragma unroll
-          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t][u].x, acc[t], 0, 0, 0);
+        for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[b & 1][t][u].x, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t][u].y, acc[t], 0, 0, 0);
+        for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[b & 1][t][u].y, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t][u].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[b & 1][t][u].z, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t][u].w, acc[t], 0, 0, 0);
-        }
-        if (b + 1 < NB) {
-#pragma unroll
-          for (int t = 0; t < TB; ++t)
-#pragma unroll
-            for (int u = 0; u < HB; ++u) w[t][u] = wn[t][u];
-        }
+        for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[b & 1][t][u].w, acc[t], 0, 0, 0);
       }
+      if (b + 2 < NB) load_batch(b + 2);
+    }
 #pragma unroll
-      for (int t = 0; t < TB; ++t) {
-        const int ct = wave + (t0 + t) * KW;
-        if (ct < NCT16) {
+    for (int t = 0; t < TB; ++t) {
+      const int ct = wave + t * KW;
+      if (ct < NCT16) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s_z[(4 * kq + r) * LDZ + ct * 16 + l15] = acc[t][r];
-        }
+        for (int r = 0; r < 4; ++r) s_z[(4 * kq + r) * LDZ + ct * 16 + l15] = acc[t][r];
       }
     }
   }
@@ -653,8 +653,15 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
   GEOBI_STAMP_BWD(3);
 
   // ---- row pass over the tile's nodes, lane = edge (feast_dev.h): the dz rows come from the LDS tile
-  rowpass_edge_node<C, LC>(s_z + (wave * NPW + lane / G) * LDZ, xa, xb, Ca, p, cvec, s_u, rowptr, col, N,
-                              tile * RT + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
+  if constexpr (RP == 1) {
+    static_assert(C == 64 && LC == 0, "staged row pass: 64 channels, node-level logits");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // the landing zone's address is wave-uniform (M0)
+    rowpass_edge_node_staged<C, LDZ>(s_z + wv * NPW * LDZ, xa, xb, Ca, p, cvec, rowptr, col, N,
+                                     tile * RT + wave * NPW + lane / G, lane / G, lane % G, dl, dpn, dcs, ld_dcs);
+  } else {
+    rowpass_edge_node<C, LC>(s_z + (wave * NPW + lane / G) * LDZ, xa, xb, Ca, p, cvec, s_u, rowptr, col, N,
+                             tile * RT + wave * NPW + lane / G, lane % G, dl, dpn, dcs, ld_dcs);
+  }
   GEOBI_STAMP_BWD(4);
 }
 
@@ -670,13 +677,14 @@ __global__ __launch_bounds__(16 * RT, 4) void feast_rowpass_fused_kernel(
 // chunk and the other seven waited at the barrier.  The ninth wave takes no part in the row pass.  100 registers per
 // lane: five waves per SIMD, so two such workgroups still share a CU.
 constexpr int KT9 = 64 * H;
-template <int COUT>
+template <int COUT, int C = 128>
 __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N,
     const float* __restrict__ gout, const float* __restrict__ out_act, float slope, const float* __restrict__ Wf,
     float* __restrict__ g_out, float* __restrict__ dl, float* __restrict__ dpn, float* __restrict__ dcs, int ld_dcs) {
-  constexpr int C = 128, CCH = 32, NCC = C / CCH;
+  constexpr int CCH = 32, NCC = C / CCH;
+  static_assert(C % CCH == 0, "whole channel chunks");
   constexpr int KC = H * CCH;                    // dz columns per chunk: head h at [32 h, 32 h + 32)
   constexpr int LDZ = KC + 4;                    // + 4: the four node groups of a wave read distinct bank quads
   constexpr int GL = COUT + 4;
@@ -1006,6 +1014,21 @@ __global__ void pack_fused_batch_kernel(PackBatch pb) {
 // Tile geometry of the fused kernels: GEOBI_TILE16 (read once): 1 = 16-row tiles / four workgroups per CU (default),
 // 0 = 32-row tiles / two workgroups per CU.  Same-box A/B knob; both forms stay under the parity tests.
 int g_tile_rows = 0;          // 0: not set yet -> GEOBI_TILE16 decides; 16 / 32 once geobi_set_tile_rows was called
+// Forms of the fused backward row pass at 64 input channels (-1: environment / built-in default; set_rowpass_form):
+//   staged   1 (default; GEOBI_ROWPASS_STAGED): neighbour rows staged through LDS, 0: lane-private row reads
+//   chunked  1: the channel-chunked kernel (32-node tiles, two chunks of 32 channels) for every 64-channel layer,
+//            0: for none; default (GEOBI_ROWPASS_CHUNKED64 unset): for Cout = 128 only -- measured 31 against 36 us
+//            there, 102 against 86 us at Cout = 32
+int g_rp_staged = -1, g_rp_chunked = -1;
+bool rp_staged() {
+  static const bool env_on = [] { const char* f = getenv("GEOBI_ROWPASS_STAGED"); return !f || atoi(f) != 0; }();
+  return g_rp_staged < 0 ? env_on : g_rp_staged != 0;
+}
+bool rp_chunked64(int Cout) {
+  static const int env = [] { const char* f = getenv("GEOBI_ROWPASS_CHUNKED64"); return f ? (atoi(f) != 0 ? 1 : 0) : -1; }();
+  const int v = g_rp_chunked < 0 ? env : g_rp_chunked;
+  return v < 0 ? Cout == 128 : v != 0;
+}
 bool tile16() {
   static const bool env_on = [] { const char* f = getenv("GEOBI_TILE16"); return !f || atoi(f) != 0; }();
   return g_tile_rows ? g_tile_rows == 16 : env_on;
@@ -1071,7 +1094,7 @@ extern "C" int geobi_debug_stamps_bwd(void* host_dst, size_t bytes) {
 #endif
 
 namespace {
-template <int C, int LC, int COUT, int RT>
+template <int C, int LC, int COUT, int RT, int RP = 0>
 int launch_rowpass_fused_rt(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                          const int* col, int N, const float* ul, const float* gout, const float* out_act, float slope,
                          const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
@@ -1082,11 +1105,11 @@ int launch_rowpass_fused_rt(const float* xa, const float* xb, int Ca, const floa
   static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
   static bool attr_set = false;
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT, RT>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT, RT, RP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_rowpass_fused_kernel<C, LC, COUT, RT><<<xcd_grid(cdiv(N, RT)), 16 * RT, lds, s>>>(
+  feast_rowpass_fused_kernel<C, LC, COUT, RT, RP><<<xcd_grid(cdiv(N, RT)), 16 * RT, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp, g_out, dl, dpn, dcs, ld_dcs);
   GEOBI_LAUNCH_OK();
   return 0;
@@ -1097,16 +1120,23 @@ int launch_rowpass_fused(const float* xa, const float* xb, int Ca, const float* 
                          const int* col, int N, const float* ul, const float* gout, const float* out_act, float slope,
                          const float* Wf, int Kp, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
                          hipStream_t s) {
-  if (tile16())
+  if (tile16()) {
+    if constexpr (C == 64 && LC == 0) {
+      // GEOBI_ROWPASS_STAGED=0 / set_rowpass_form: the lane-private row reads (same-box A/B; results are bit-identical)
+      if (rp_staged() && Ca % 32 == 0)
+        return launch_rowpass_fused_rt<C, LC, COUT, 16, 1>(xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf,
+                                                           Kp, g_out, dl, dpn, dcs, ld_dcs, s);
+    }
     return launch_rowpass_fused_rt<C, LC, COUT, 16>(xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp,
                                                     g_out, dl, dpn, dcs, ld_dcs, s);
+  }
   return launch_rowpass_fused_rt<C, LC, COUT, 32>(xa, xb, Ca, p, cvec, rowptr, col, N, ul, gout, out_act, slope, Wf, Kp,
                                                   g_out, dl, dpn, dcs, ld_dcs, s);
 }
 }  // namespace
 
 namespace {
-template <int COUT>
+template <int COUT, int C = 128>
 int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const float* p, const float* cvec,
                             const int* rowptr, const int* col, int N, const float* gout, const float* out_act,
                             float slope, const float* Wf, float* g_out, float* dl, float* dpn, float* dcs, int ld_dcs,
@@ -1115,16 +1145,25 @@ int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const floa
   static_assert(lds <= 81920, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused128_kernel<COUT>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused128_kernel<COUT, C>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_rowpass_fused128_kernel<COUT><<<xcd_grid(cdiv(N, TN)), KT9, lds, s>>>(
+  feast_rowpass_fused128_kernel<COUT, C><<<xcd_grid(cdiv(N, TN)), KT9, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn, dcs, ld_dcs);
   GEOBI_LAUNCH_OK();
   return 0;
 }
 }  // namespace
+
+// forms of the 64-channel backward row pass from one process (parity tests, A/B timing): 1 / 0, -1 = default
+int set_rowpass_form(int staged, int chunked64) {
+  if (staged < -1 || staged > 1 || chunked64 < -1 || chunked64 > 1)
+    return set_error("row-pass form: staged and chunked64 are 1, 0 or -1 (default), got %d, %d", staged, chunked64);
+  g_rp_staged = staged;
+  g_rp_chunked = chunked64;
+  return 0;
+}
 
 // both tile geometries from one process (parity tests, A/B timing): rows = 16 / 32, 0 = back to GEOBI_TILE16
 int set_tile_rows(int rows) {
@@ -1165,6 +1204,20 @@ int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const
       return launch_rowpass_fused128<128>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl, dpn,
                                           dcs, ld_dcs, s);
     return set_error("feast fused row pass: unsupported Cout=%d at 128 input channels", Cout);
+  }
+  {
+    // the channel-chunked kernel (32-node tiles, half the weight bytes per node) at 64 input channels: see rp_chunked64
+    if (Cin == 64 && LC == 0 && (Ca == Cin || Ca % 32 == 0) && rp_chunked64(Cout)) {
+      if (Cout == 32)
+        return launch_rowpass_fused128<32, 64>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl,
+                                               dpn, dcs, ld_dcs, s);
+      if (Cout == 64)
+        return launch_rowpass_fused128<64, 64>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl,
+                                               dpn, dcs, ld_dcs, s);
+      if (Cout == 128)
+        return launch_rowpass_fused128<128, 64>(xa, xb, Ca, p, cvec, rowptr, col, N, gout, out_act, slope, Wf, g_out, dl,
+                                                dpn, dcs, ld_dcs, s);
+    }
   }
   switch (Cin * 100 + LC) {
     case 600: GEOBI_RP_COUT(6, 0)

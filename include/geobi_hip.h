@@ -124,6 +124,14 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
  * Process-wide; for parity tests and same-process A/B timing.                                                       */
 int geobi_set_tile_rows(int rows);
 
+/* Form of the fused backward row pass of layers reading 64 channels; each argument 1, 0 or -1 (= default).
+ * staged (default 1, GEOBI_ROWPASS_STAGED): the neighbour rows reach the lane = edge dot products through LDS
+ *   (global_load_lds_dwordx4, half a row per eight lanes) instead of sixteen private 16-B reads per lane; bit-identical.
+ * chunked64 (default: Cout = 128 only, GEOBI_ROWPASS_CHUNKED64): the channel-chunked kernel of the 128-channel layers
+ *   (32-node tiles, 32 channels at a time) instead of the 16-node-tile kernel.
+ * Process-wide; for parity tests and same-process A/B timing.                                                       */
+int geobi_set_rowpass_form(int staged, int chunked64);
+
 /* ---------------------------------------------------------------- pooling ------------------
  * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10
  *                         (code/net_util.py:226-230):  w_out = w_in + exp(-|x_row - x_col|^2 / 2)

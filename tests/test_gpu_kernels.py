@@ -166,6 +166,29 @@ def test_feast_conv_random_graph(dev, Cin, Cout, slope, split, fused):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize('Cout,slope,split', [(32, 0.2, False), (32, 1.0, True), (64, 0.2, True), (128, 0.2, False)])
+def test_feast_rowpass_forms_at_64_channels(dev, Cout, slope, split):
+    """The fused backward row pass of a 64-channel layer has three forms (geobi_set_rowpass_form): lane-private row reads,
+    rows staged through LDS by global_load_lds (default), and the channel-chunked 32-node-tile kernel (default at
+    Cout = 128).  Every form against the fp64 oracle on a graph with isolated nodes and a hub of in-degree 200+ (several
+    chunks of 16 items per node, ragged last tile); staged and lane-private run the same FMAs in the same order."""
+    from geobi_gnn_amd import _lib as L
+    n = 333
+    g = torch.Generator().manual_seed(Cout)
+    ei = torch.randint(0, n - 20, (2, 3000), generator=g)
+    hub = torch.stack([torch.arange(1, 201), torch.zeros(200, dtype=torch.long)])
+    ei = torch.cat([ei, hub], 1)
+    got = {}
+    try:
+        for form in ((0, 0), (1, 0), (0, 1)):
+            L.call('geobi_set_rowpass_form', *form)
+            got[form] = _run_feast(dev, 64, Cout, ei, n, slope, split, seed=17 + Cout)
+            assert max(got[form].values()) < TOL, (form, got[form])
+    finally:
+        L.call('geobi_set_rowpass_form', -1, -1)
+    assert got[(0, 0)] == got[(1, 0)], (got[(0, 0)], got[(1, 0)])       # bit-identical results -> identical errors
+
+
 def test_feast_conv_directed_graph_and_isolated_nodes(dev):
     """Non-symmetric edges, duplicate edges kept, nodes without neighbours, degree > 64."""
     n = 300
