@@ -354,6 +354,9 @@ __device__ __forceinline__ void rowpass_edge_node(
 // lane = item reads (ds_read_b128, lane k at (k >> 1) x 1040 + (k & 1) x 128) conflict-free.  Lane k of a group then
 // runs the same FMAs in the same order as above (channels ascending): the results are bit-identical.
 // Per chunk of 16 items: two staged halves = two round trips instead of four, an eighth of the cache-line lookups.
+#ifndef GEOBI_RP_STAMP
+#define GEOBI_RP_STAMP(i) do { } while (0)
+#endif
 template <int L>
 __device__ __forceinline__ int row_bcast(int v) {             // lane L of every 16-lane row -> the whole row
   return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xf, 0xf, false);   // row_newbcast:L
@@ -364,6 +367,8 @@ __device__ __forceinline__ void rowpass_edge_node_staged(
     float* wave_rows, const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col, int N, int node, int g,
     int k, float* __restrict__ dl, float* __restrict__ dpn, float* __restrict__ dcs, int ld_dcs) {
+  // (Row pointers and neighbour ids requested by the kernel ahead of its matrix phase -- two dependent loads off this
+  // function's chain -- measured 101 against 99 us: the workgroups of a CU cover each other's waits already.)
   constexpr int G = 16, HALF = 32, HQ = HALF / 4;             // 16 pieces per head (= G), 8 per half row
   constexpr int SLOT = 260;                                   // floats between two staging instructions (1 KiB + 16 B)
   static_assert(C == 64, "a row is two 128-B halves");
@@ -425,10 +430,12 @@ __device__ __forceinline__ void rowpass_edge_node_staged(
     float sv[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) sv[h] = 0.f;
+    if (base == 0) GEOBI_RP_STAMP(5);
     static_for<0, 2>([&](auto halfc) {
       constexpr int half = decltype(halfc)::value;
       if constexpr (half == 1) stage(halfc);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the half rows have landed
+      if (base == 0) GEOBI_RP_STAMP(6 + half);
       static_for<0, HQ / 4>([&](auto bi) {
         constexpr int q0 = decltype(bi)::value * 4;
         float xj[4][4];

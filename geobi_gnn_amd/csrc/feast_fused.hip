@@ -25,6 +25,11 @@
 //                    columns [dp | dcs] read from `dpd`; output split into (dxa | dxb) for split inputs.
 #include "common.h"
 #include <type_traits>
+#ifdef GEOBI_FUSED_STAMPS
+// diagnostic build: the staged row pass (feast_dev.h) stamps its own steps into the backward kernel's buffer
+namespace geobi { namespace { __device__ unsigned long long g_stamps_bwd[16384][8]; } }
+#define GEOBI_RP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) ::geobi::g_stamps_bwd[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "feast_dev.h"
 
 namespace geobi {
@@ -101,7 +106,6 @@ constexpr int fused_k(int C, int MODE) { return ((MODE == 0 ? H * C : H * C + 2 
 // Diagnostic build only (tools/build_variant.sh ... -DGEOBI_FUSED_STAMPS): shader-clock stamps of wave 0 of each
 // workgroup at the phase boundaries, written to a buffer nothing else reads.
 __device__ unsigned long long g_stamps[16384][8];
-__device__ unsigned long long g_stamps_bwd[16384][8];       // the fused backward row pass keeps its own set
 #define GEOBI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define GEOBI_STAMP_BWD(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps_bwd[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else

@@ -33,5 +33,12 @@ print('layer %d->%d backward, %d tiles; s_memtime ticks per phase, mean / median
 for i, nme in enumerate(names):
     print('  %-28s %9.0f %9.0f %9.0f' % (nme, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
 print('  %-28s %9.0f' % ('whole tile (wave 0)', (t[:, 4] - t[:, 0]).mean()))
+f = buf[:nb, :8].astype(np.int64)
+if (f[:, 5:8] > 0).all():        # staged row pass (64 channels): its own steps, first chunk of items of wave 0's nodes
+    seq = np.stack([f[:, 3], f[:, 5], f[:, 6], f[:, 7], f[:, 4]], 1)
+    dd = np.diff(seq, axis=1)
+    for i, nme in enumerate(['  dz pieces, ids, logits, softmax', '  wait: first half rows', '  FMAs + wait: second half rows',
+                             '  FMAs, dl rows, node sums']):
+        print('  %-34s %9.0f %9.0f %9.0f' % (nme, dd[:, i].mean(), np.median(dd[:, i]), np.percentile(dd[:, i], 90)))
 span = t[:, 4].max() - t[:, 0].min()
 print('  span first start -> last end: %d ticks; tiles in flight on average: %.1f' % (span, (t[:, 4] - t[:, 0]).sum() / span))
