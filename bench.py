@@ -106,6 +106,11 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
     # launch; the dominant layer runs on both level-0 graphs, N averaged over its launches)
     n_avg = (dv.x.shape[0] + df.x.shape[0]) / 2.0
     tflops = 2.0 * n_avg * 9 * best['cin'] * best['cout'] / (avg_us * 1e-6) / 1e12
+    # ... and the aggregation beside it: 2 x 9 Cin flops per (edge + self loop) as packed FMAs.  fp32 MFMA and VALU work do
+    # not overlap on a gfx950 SIMD (profiles/r03_overlap_probe.txt): the two shares of the kernel meet ONE 64 flop / cycle
+    # / SIMD ceiling, numerically the fp32 MFMA peak
+    e_avg = delivered_edges(dv, df) / 2.0
+    tflops_all = tflops + 2.0 * e_avg * 9 * best['cin'] / (avg_us * 1e-6) / 1e12
     out = {
         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(ach / HBM_PEAK_GBS, 4),
@@ -117,6 +122,10 @@ def measure_roofline(net, bucket, opt, dv, df, steps=3):
         'mfma_side': {'achieved': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                       'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
                       'note': 'valid when the dominant layer is a level-0 layer (64 -> 32 on the bench workload)'},
+        'fp32_side': {'achieved': round(tflops_all, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(tflops_all / MFMA_F32_PEAK_TFLOPS, 4),
+                      'note': 'node transform (matrix cores) + aggregation (packed FMAs) against the one fp32 ceiling of a '
+                              'SIMD: the two do not overlap on gfx950 (profiles/r03_overlap_probe.txt)'},
         'launches': best['launches'], 'avg_us': round(avg_us, 2),
         'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
         'all_instantiations': {'launches': total['launches'],
