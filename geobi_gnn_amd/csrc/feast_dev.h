@@ -188,6 +188,31 @@ __device__ __forceinline__ void fmac_bcast(float& acc, const float* dz, const fl
 #undef GEOBI_FB
 }
 
+// Three heads at a time: acc_t += sum_v (lane O_t's dz_t[v]) * x[v] for one 16-B piece, the three accumulators taking turns
+// (no FMA waits on the one before it) behind ONE pair of wait states -- a third of the s_nops of the per-head form above
+// (144 -> 48 per 16 items of a 64-channel row), same FMAs in the same order per accumulator.
+template <int O0, int O1, int O2>
+__device__ __forceinline__ void fmac_bcast3(float& a0, float& a1, float& a2, const float* d0, const float* d1, const float* d2,
+                                            const float* x) {
+  static_assert(O0 >= 0 && O0 < 16 && O1 >= 0 && O1 < 16 && O2 >= 0 && O2 < 16, "a DPP row has 16 lanes");
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %3, %15 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %7, %15 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %11, %15 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %4, %16 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %8, %16 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %12, %16 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %5, %17 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %9, %17 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %13, %17 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %6, %18 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %10, %18 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %14, %18 row_newbcast:%21 row_mask:0xf bank_mask:0xf"
+      : "+v"(a0), "+v"(a1), "+v"(a2)
+      : "v"(d0[0]), "v"(d0[1]), "v"(d0[2]), "v"(d0[3]), "v"(d1[0]), "v"(d1[1]), "v"(d1[2]), "v"(d1[3]), "v"(d2[0]),
+        "v"(d2[1]), "v"(d2[2]), "v"(d2[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "n"(O0), "n"(O1), "n"(O2));
+}
+
 // f(integral_constant<int, I>) for I in [0, N): loop indices that must be constants (DPP controls, register slots)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -304,11 +329,19 @@ __device__ __forceinline__ void rowpass_edge_node(
         for (int qd = 0; qd < XB; ++qd) load_piece<VW>(src + ch0 + qd * VW, xj[qd]);
         static_for<0, XB>([&](auto qi) {
           constexpr int qd = decltype(qi)::value;
-          static_for<0, H>([&](auto hi) {
-            constexpr int h = decltype(hi)::value;
-            constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
-            fmac_bcast<owner, VW>(sv[h], dzr[sl], xj[qd]);
-          });
+          if constexpr (VW == 4) {
+            static_for<0, H / 3>([&](auto gi) {
+              constexpr int h = decltype(gi)::value * 3;
+              constexpr int p0 = h * NQ + q0 + qd, p1 = p0 + NQ, p2 = p1 + NQ;
+              fmac_bcast3<p0 % G, p1 % G, p2 % G>(sv[h], sv[h + 1], sv[h + 2], dzr[p0 / G], dzr[p1 / G], dzr[p2 / G], xj[qd]);
+            });
+          } else {
+            static_for<0, H>([&](auto hi) {
+              constexpr int h = decltype(hi)::value;
+              constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
+              fmac_bcast<owner, VW>(sv[h], dzr[sl], xj[qd]);
+            });
+          }
         });
       });
     });
@@ -445,9 +478,9 @@ __device__ __forceinline__ void rowpass_edge_node_staged(
         for (int qd = 0; qd < 4; ++qd) load_piece<4>(my + (q0 + qd) * 4, xj[qd]);
         static_for<0, 4>([&](auto qi) {
           constexpr int qd = decltype(qi)::value;
-          static_for<0, H>([&](auto hi) {
-            constexpr int h = decltype(hi)::value;
-            fmac_bcast<half * HQ + q0 + qd, 4>(sv[h], dzr[h], xj[qd]);
+          static_for<0, H / 3>([&](auto gi) {
+            constexpr int h = decltype(gi)::value * 3, o = half * HQ + q0 + qd;
+            fmac_bcast3<o, o, o>(sv[h], sv[h + 1], sv[h + 2], dzr[h], dzr[h + 1], dzr[h + 2], xj[qd]);
           });
         });
       });

@@ -809,10 +809,10 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
           for (int qd = 0; qd < 4; ++qd) load_piece<4>(src + (q0 + qd) * 4, xj[qd]);
           static_for<0, 4>([&](auto qi) {
             constexpr int qd = decltype(qi)::value;
-            static_for<0, H>([&](auto hi) {
-              constexpr int h = decltype(hi)::value;
-              constexpr int pidx = h * NQ + q0 + qd, sl = pidx / G, owner = pidx % G;
-              fmac_bcast<owner, 4>(sv[h], dzr[sl], xj[qd]);
+            static_for<0, H / 3>([&](auto gi) {
+              constexpr int h = decltype(gi)::value * 3;
+              constexpr int p0 = h * NQ + q0 + qd, p1 = p0 + NQ, p2 = p1 + NQ;
+              fmac_bcast3<p0 % G, p1 % G, p2 % G>(sv[h], sv[h + 1], sv[h + 2], dzr[p0 / G], dzr[p1 / G], dzr[p2 / G], xj[qd]);
             });
           });
         });
