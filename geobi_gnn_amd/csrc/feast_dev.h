@@ -16,8 +16,24 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (expf here is ocml's: 13 instructions, <= 1 ulp.  A two-instruction v_exp_f32(x log2 e) -- absolute error of a softmax
-// term <= 2e-8 -- passed every parity test but bought 1.2 % of the fused kernels' time: not taken, profiles/r03_overlap_probe.txt.)
+// exp(x) for the softmax terms (x <= 0 once the maximum is subtracted; finite logits).  ocml's expf spends 13
+// instructions per call, 9 calls per edge in three kernels: product, residual of the product and the low part of log2 e,
+// integer / fraction split, v_exp_f32, ldexp, two range selects.  v_exp_f32 takes the whole argument at 1 ulp (the
+// fraction of a float is exact), so the split and the selects are not needed: exp2(t) with t = fl(x log2 e) and the
+// residual e = x log2 e - t applied to first order, 2^e = 1 + e ln 2 (|e| <= 2^-18: second order 2^-37).  6 instructions,
+// the same <= 2 ulp; -3 % on the forward kernel (GEOBI_EXP_OCML=1 in a variant build restores expf).
+__device__ __forceinline__ float exp_le0(float x) {
+#ifdef GEOBI_EXP_OCML
+  return expf(x);
+#else
+  const float t = x * 1.44269502e+00f;                       // 0x3fb8aa3b
+  float e = fmaf(x, 1.44269502e+00f, -t);
+  e = fmaf(x, 1.92596299e-08f, e);                            // 0x32a5705f: log2 e - fl(log2 e)
+  const float r = __builtin_amdgcn_exp2f(t);                  // v_exp_f32; 0 below 2^-126
+  return fmaf(r, e * 6.93147182e-01f, r);
+#endif
+}
+
 __device__ __forceinline__ void softmax9(float (&l)[H]) {
   float m = l[0];
 #pragma unroll
@@ -25,7 +41,7 @@ __device__ __forceinline__ void softmax9(float (&l)[H]) {
   float s = 0.f;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    l[h] = expf(l[h] - m);
+    l[h] = exp_le0(l[h] - m);
     s += l[h];
   }
   float inv = 1.0f / s;
