@@ -1,28 +1,31 @@
 // FeaSt layer, fused form: aggregation + node-level transform in ONE kernel -- the aggregated rows
 // z_i = [1/deg sum_j q_ijh x_j]_h (9*C floats per node) never reach HBM.
 //
-// A workgroup (8 waves) owns a tile of 32 consecutive nodes:
-//   phase A  the gather of feast.hip's aggregation kernel (G = C/VEC lanes per node, per-edge softmax
-//            evaluated once and parked, neighbour rows gathered as one contiguous segment per row), but
-//            the 9 x VEC register accumulators of a node are stored into an LDS tile z[32][LD] instead of
-//            global memory.  The per-edge parking slots live in the first 3C floats of the node's own
-//            (not yet written) tile row, so the tile is the kernel's only LDS.
-//   phase B  out[32, NOUT] = z[32, K] * Bp[K, NOUT] on the matrix cores (v_mfma_f32_32x32x2_f32, exact
-//            fp32).  The 8 waves split the NOUT/32 column tiles and the K range; the K-split partial tiles
-//            are folded through LDS in a fixed order (deterministic), bias + leaky-relu applied, rows
-//            written with 8-B stores (one 128-B segment per 16 lanes).
-// Operand delivery: the weights are packed so that ONE 16-B load per lane feeds four consecutive MFMAs,
-//   Bp[kb][half][col][s] = B[k = 8 kb + 4 half + s][col],
-// and the A operand is the matching 16 B of the lane's tile row, z[lane & 31][8 kb + 4 half .. + 3]
-// (ds_read_b128; LD = 4 mod 64 floats makes it conflict-free).  The MFMA's two k-slots of step s are thus
-// k = 8 kb + s (lanes 0-31) and k = 8 kb + 4 + s (lanes 32-63): any bijection works as long as A and B
-// agree; the order of the fp32 sum is fixed by it and does not depend on N or on the batch.
+// A workgroup owns a tile of consecutive nodes -- 16 nodes / 4 waves (default, four workgroups per CU) or 32 nodes /
+// 8 waves (round-2 geometry; `Shape`, GEOBI_TILE16, geobi_set_tile_rows):
+//   phase A  the gather of feast.hip's aggregation kernel (16 lanes per node, per-edge softmax evaluated once and
+//            parked, neighbour rows gathered as one contiguous segment per row), but the 9 x VEC register
+//            accumulators of a node are stored into an LDS tile z[rows][LD] instead of global memory.  The per-edge
+//            parking slots live in the first 3C floats of the node's own (not yet written) tile row, so the tile is
+//            the kernel's only LDS.
+//   phase B  out[rows, NOUT] = z[rows, K] * Bp[K, NOUT] on the matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2, exact
+//            fp32).  The waves split the column tiles and the K range; the K-split partial tiles are folded through
+//            LDS in a fixed order (deterministic), bias + leaky-relu applied, rows written with 8-B stores (one
+//            128-B segment per 16 lanes).
+// Operand delivery: the weights are packed so that ONE 16-B load per lane feeds four consecutive MFMAs in either shape,
+//   Bp[k / 4][col][k % 4] = B[k][col]           (K padded to 16),
+// and the A operand is the matching 16 B of the lane's tile row (ds_read_b128; the row stride keeps it conflict-free).
+// Any bijection between k-slots and lanes works as long as A and B agree; the order of the fp32 sum is fixed by it and
+// does not depend on N or on the batch.
 //
-// MODE 0  forward:   rows = layer input (xa | xb), K = 9 Cin padded to 8, Bp from lin.weight, epilogue
-//                    bias + leaky-relu.
+// MODE 0  forward:   rows = layer input (xa | xb), K = 9 Cin, Bp from lin.weight, epilogue bias + leaky-relu.
 // MODE 1  backward:  dx = [r | dp | dcs] [lin.weight ; u.weight ; 0]: rows = g (gradient w.r.t. the
 //                    pre-activation output), transposed CSR, weights q_ij / deg_i; the tile gets 24 extra
-//                    columns [dp | dcs] read from `dpd`; output split into (dxa | dxb) for split inputs.
+//                    columns [dp | dcs] -- dp summed in the kernel from the row pass' dl rows, dcs read from
+//                    `dpd`; output split into (dxa | dxb) for split inputs; the tile rows r' are written out
+//                    once for the weight-gradient product.
+// The backward's first half (g, dz = g Wf^T on the matrix cores, per-edge softmax backward) is
+// feast_rowpass_fused_kernel / feast_rowpass_fused128_kernel below.
 #include "common.h"
 #include <type_traits>
 #ifdef GEOBI_FUSED_STAMPS
