@@ -94,21 +94,22 @@ static inline size_t gemm_nn_ws_bytes(int64_t M, int N) {
 int feast_fused_nt(int nout);
 size_t feast_fused_fwd_pack_floats(int Cin, int Cout);
 size_t feast_fused_dx_pack_floats(int Cin, int Cout);
-int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s);
+int feast_fused_pack_fwd(const float* lin_w, const float* c, int Cin, int Cout, float* bp, hipStream_t s);
 // one launch for the packed forms of several layers (feast_fused.hip)
 constexpr int kMaxPackBatch = 8;
 struct FusedPackItem {
   const float* lin_w;
   const float* u_w;
+  const float* c;
   int Cin, Cout;
   float* wf;     // [Kp, Cout] plain form (NULL: forward form only)
   float* bf;     // fragment-ordered forward weights
   float* bdx;    // fragment-ordered dx weights (with wf)
 };
 int feast_fused_pack_batch(const FusedPackItem* items, int n, hipStream_t s);
-int feast_fused_pack_dx(const float* lin_w, const float* u_w, int Cin, int Cout, float* bp, hipStream_t s);
-int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout, int Kp, float* wf, float* bf,
-                         float* bdx, hipStream_t s);
+int feast_fused_pack_dx(const float* lin_w, const float* u_w, const float* c, int Cin, int Cout, float* bp, hipStream_t s);
+int feast_fused_pack_all(const float* lin_w, const float* u_w, const float* c, int Cin, int Cout, int Kp, float* wf,
+                         float* bf, float* bdx, hipStream_t s);
 double feast_fused_bytes(int64_t N, int64_t E, int C, int nout);
 int feast_fused_fwd(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
                     const int* rowptr, const int* col, int N, int LC, const float* ul, const float* Bp, int Cout,

@@ -311,7 +311,8 @@ int gnn_forward(Bump& b, const Level& L0, const float* x_in, int Cin, const geob
       const int ci = plan[i][0], co = plan[i][1];
       pk[i] = b.take<float>(tape ? feast_wpack_floats(ci, co) : feast_fused_fwd_pack_floats(ci, co));
       if (!b.ok) return kArenaFull;
-      items[i].lin_w = p.conv[i].lin_w; items[i].u_w = p.conv[i].u_w; items[i].Cin = ci; items[i].Cout = co;
+      items[i].lin_w = p.conv[i].lin_w; items[i].u_w = p.conv[i].u_w; items[i].c = p.conv[i].c;
+      items[i].Cin = ci; items[i].Cout = co;
       if (tape) {
         items[i].wf = pk[i];
         items[i].bf = pk[i] + feast_wpack_plain_floats(ci, co);

@@ -703,9 +703,10 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
       // packed by the caller
     } else if (wf_out != nullptr) {      // + the backward's packed forms (Wf for dz, the fused dx weights), one launch
       float* bfw = wf_out + plain;
-      GEOBI_TRY(feast_fused_pack_all(lin_w, u_w, Cin, Cout, Kp, wf_out, bfw, bfw + feast_fused_fwd_pack_floats(Cin, Cout), s));
+      GEOBI_TRY(feast_fused_pack_all(lin_w, u_w, cvec, Cin, Cout, Kp, wf_out, bfw,
+                                     bfw + feast_fused_fwd_pack_floats(Cin, Cout), s));
     } else {
-      GEOBI_TRY(feast_fused_pack_fwd(lin_w, Cin, Cout, const_cast<float*>(bf), s));
+      GEOBI_TRY(feast_fused_pack_fwd(lin_w, cvec, Cin, Cout, const_cast<float*>(bf), s));
     }
     const int LCf = edge_logit_channels(Cin, Cb);
     if (LCf == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
@@ -934,7 +935,7 @@ int feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     if (wf_saved != nullptr) {
       bdx = wf_saved + feast_wpack_plain_floats(Cin, Cout) + feast_fused_fwd_pack_floats(Cin, Cout);
     } else {
-      GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, Cin, Cout, b.bdx, s));
+      GEOBI_TRY(feast_fused_pack_dx(lin_w, u_w, cvec, Cin, Cout, b.bdx, s));
     }
     prof_begin(PROF_AGG_BWD, s, feast_fused_bytes(N, Ecap, Cout, Cin), Cout);
     rc = feast_fused_dx(g, Cout, p, cvec, rowptr_out, col_out, rowptr_in, pos_in, b.dl, b.dpn, (int)N, LC, xa, u_w, dpd,

@@ -159,9 +159,10 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
       if (c0 < Ca) { fb[q] = xa + c0; fs[q] = Ca; } else { fb[q] = xb + (c0 - Ca); fs[q] = C - Ca; }
     }
     float cc[H], qs[H];
+    // the self edge: u(x_i - x_i) + c = c exactly; its softmax is the same for every node: packed behind the weights
+    const float* qself = Bp + (size_t)fused_k(C, MODE) * 32 * NT;
 #pragma unroll
-    for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = cc[h]; }
-    softmax9(qs);   // the self edge: u(x_i - x_i) + c = c exactly
+    for (int h = 0; h < H; ++h) { cc[h] = cvec[h]; qs[h] = qself[h]; }
 
     const int ns = valid ? node : N - 1;
     const int rs = rowptr[ns];
@@ -903,12 +904,31 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
   bq[2] = make_float4(dsum[8] + dself[8], 0.f, 0.f, 0.f);
 }
 
+// Behind the packed weights of either kernel mode: QSELF floats = softmax(c), the attention weights of the self loop
+// (u (x_i - x_i) + c = c exactly) -- the same nine numbers for every node of a layer, which every wave of the fused kernels
+// used to recompute at its start (nine exps + the softmax around them: ~85 of a wave's ~730 vector instructions per tile).
+constexpr int QSELF = 12;
+__device__ __forceinline__ float pack_qself(const float* __restrict__ c, int i) {
+  if (i >= H) return 0.f;
+  float q[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) q[h] = c[h];
+  softmax9(q);
+  float v = 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) v = h == i ? q[h] : v;
+  return v;
+}
+
 // Packed weights of the forward:  Bp[kb][half][col][s] = lin.weight[h * Cout + col, kin] for k = 8 kb + 4 half + s
 // = h * Cin + kin (zero for k >= 9 Cin or col >= Cout), NP = padded column count (multiple of 32).
-__global__ void pack_fused_fwd_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int KD, int NP,
-                                      float* __restrict__ bp) {
+__global__ void pack_fused_fwd_kernel(const float* __restrict__ lin_w, const float* __restrict__ c, int Cin, int Cout,
+                                      int KD, int NP, float* __restrict__ bp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= KD * NP) return;
+  if (idx >= KD * NP) {
+    if (idx < KD * NP + QSELF) bp[idx] = pack_qself(c, idx - KD * NP);
+    return;
+  }
   const int s = idx & 3, colx = (idx >> 2) % NP, rest = (idx >> 2) / NP;
   const int hf = rest & 1, kb = rest >> 1;
   const int k = 8 * kb + 4 * hf + s;
@@ -919,10 +939,14 @@ __global__ void pack_fused_fwd_kernel(const float* __restrict__ lin_w, int Cin, 
 
 // Packed weights of dx = r' W':  rows k < 9 Cout: lin.weight[k, col]; the next 9: u.weight[k - 9 Cout, col];
 // the remaining 15 rows ([dp] padding and the dcs columns of r') are zero.
-__global__ void pack_fused_dx_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w, int Cin, int Cout,
-                                     int KD, int NP, float* __restrict__ bp) {
+__global__ void pack_fused_dx_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w,
+                                     const float* __restrict__ c, int Cin, int Cout, int KD, int NP,
+                                     float* __restrict__ bp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= KD * NP) return;
+  if (idx >= KD * NP) {
+    if (idx < KD * NP + QSELF) bp[idx] = pack_qself(c, idx - KD * NP);
+    return;
+  }
   const int s = idx & 3, colx = (idx >> 2) % NP, rest = (idx >> 2) / NP;
   const int hf = rest & 1, kb = rest >> 1;
   const int k = 8 * kb + 4 * hf + s;
@@ -937,11 +961,17 @@ __global__ void pack_fused_dx_kernel(const float* __restrict__ lin_w, const floa
 // Training forward: every packed form the layer's forward AND backward need, in one launch --
 //   wf  [Kp, Cout]      row h Cin + k = lin.weight[h Cout + o, k]      (dz = g Wf^T in the backward)
 //   bf  fragment-ordered forward weights (pack_fused_fwd_kernel),  bdx  fragment-ordered dx weights.
-__global__ void pack_fused_all_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w, int Cin, int Cout,
-                                      int Kp, int KDf, int NPf, int KDx, int NPx, float* __restrict__ wf,
-                                      float* __restrict__ bf, float* __restrict__ bdx) {
+__global__ void pack_fused_all_kernel(const float* __restrict__ lin_w, const float* __restrict__ u_w,
+                                      const float* __restrict__ c, int Cin, int Cout, int Kp, int KDf, int NPf, int KDx,
+                                      int NPx, float* __restrict__ wf, float* __restrict__ bf, float* __restrict__ bdx) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_wf = Kp * Cout, n_bf = KDf * NPf, n_bx = KDx * NPx;
+  if (idx >= n_wf + n_bf + n_bx) {           // the two softmax(c) tails
+    const int t = idx - (n_wf + n_bf + n_bx);
+    if (t < QSELF) bf[n_bf + t] = pack_qself(c, t);
+    else if (t < 2 * QSELF) bdx[n_bx + t - QSELF] = pack_qself(c, t - QSELF);
+    return;
+  }
   if (idx < n_wf) {
     const int kk = idx / Cout, o = idx % Cout;
     const int h = kk / Cin, k = kk % Cin;
@@ -990,6 +1020,12 @@ __global__ void pack_fused_batch_kernel(PackBatch pb) {
   const int KDf = fused_k(Cin, 0), NPf = 32 * (Cout <= 32 ? 1 : (Cout <= 64 ? 2 : 4));
   const int KDx = fused_k(Cout, 1), NPx = 32 * (Cin <= 32 ? 1 : (Cin <= 64 ? 2 : 4));
   const int n_wf = pb.all ? Kp * Cout : 0, n_bf = KDf * NPf, n_bx = pb.all ? KDx * NPx : 0;
+  if (idx >= n_wf + n_bf + n_bx) {           // the softmax(c) tails behind bf (and bdx)
+    const int t = idx - (n_wf + n_bf + n_bx);
+    if (t < QSELF) d.bf[n_bf + t] = pack_qself(d.c, t);
+    else if (pb.all && t < 2 * QSELF) d.bdx[n_bx + t - QSELF] = pack_qself(d.c, t - QSELF);
+    return;
+  }
   if (idx < n_wf) {
     const int kk = idx / Cout, o = idx % Cout;
     const int h = kk / Cin, k = kk % Cin;
@@ -1240,21 +1276,22 @@ int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const
 }
 
 int feast_fused_nt(int nout) { return nout <= 32 ? 1 : (nout <= 64 ? 2 : 4); }
-size_t feast_fused_fwd_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout); }
-size_t feast_fused_dx_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cout, 1) * 32 * feast_fused_nt(Cin); }
+// packed weights + the QSELF floats softmax(c) behind them
+size_t feast_fused_fwd_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout) + QSELF; }
+size_t feast_fused_dx_pack_floats(int Cin, int Cout) { return (size_t)fused_k(Cout, 1) * 32 * feast_fused_nt(Cin) + QSELF; }
 
-int feast_fused_pack_fwd(const float* lin_w, int Cin, int Cout, float* bp, hipStream_t s) {
+int feast_fused_pack_fwd(const float* lin_w, const float* c, int Cin, int Cout, float* bp, hipStream_t s) {
   const int KD = fused_k(Cin, 0), NP = 32 * feast_fused_nt(Cout);
-  pack_fused_fwd_kernel<<<cdiv((int64_t)KD * NP, 256), 256, 0, s>>>(lin_w, Cin, Cout, KD, NP, bp);
+  pack_fused_fwd_kernel<<<cdiv((int64_t)KD * NP + QSELF, 256), 256, 0, s>>>(lin_w, c, Cin, Cout, KD, NP, bp);
   GEOBI_LAUNCH_OK();
   return 0;
 }
 
-int feast_fused_pack_all(const float* lin_w, const float* u_w, int Cin, int Cout, int Kp, float* wf, float* bf,
-                         float* bdx, hipStream_t s) {
+int feast_fused_pack_all(const float* lin_w, const float* u_w, const float* c, int Cin, int Cout, int Kp, float* wf,
+                         float* bf, float* bdx, hipStream_t s) {
   const int KDf = fused_k(Cin, 0), NPf = 32 * feast_fused_nt(Cout), KDx = fused_k(Cout, 1), NPx = 32 * feast_fused_nt(Cin);
-  const int64_t total = (int64_t)Kp * Cout + (int64_t)KDf * NPf + (int64_t)KDx * NPx;
-  pack_fused_all_kernel<<<cdiv(total, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, Kp, KDf, NPf, KDx, NPx, wf, bf, bdx);
+  const int64_t total = (int64_t)Kp * Cout + (int64_t)KDf * NPf + (int64_t)KDx * NPx + 2 * QSELF;
+  pack_fused_all_kernel<<<cdiv(total, 256), 256, 0, s>>>(lin_w, u_w, c, Cin, Cout, Kp, KDf, NPf, KDx, NPx, wf, bf, bdx);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -1271,8 +1308,8 @@ int feast_fused_pack_batch(const FusedPackItem* items, int n, hipStream_t s) {
     pb.it[i] = items[i];
     const int Cin = items[i].Cin, Cout = items[i].Cout;
     GEOBI_REQUIRE((items[i].wf != nullptr) == (pb.all != 0), "pack batch: mixed modes");
-    int64_t cnt = (int64_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout);
-    if (pb.all) cnt += (int64_t)feast_ldz(Cin) * Cout + (int64_t)fused_k(Cout, 1) * 32 * feast_fused_nt(Cin);
+    int64_t cnt = (int64_t)fused_k(Cin, 0) * 32 * feast_fused_nt(Cout) + QSELF;
+    if (pb.all) cnt += (int64_t)feast_ldz(Cin) * Cout + (int64_t)fused_k(Cout, 1) * 32 * feast_fused_nt(Cin) + QSELF;
     pb.start[i + 1] = pb.start[i] + cnt;
   }
   pack_fused_batch_kernel<<<cdiv(pb.start[n], 256), 256, 0, s>>>(pb);
@@ -1280,9 +1317,10 @@ int feast_fused_pack_batch(const FusedPackItem* items, int n, hipStream_t s) {
   return 0;
 }
 
-int feast_fused_pack_dx(const float* lin_w, const float* u_w, int Cin, int Cout, float* bp, hipStream_t s) {
+int feast_fused_pack_dx(const float* lin_w, const float* u_w, const float* c, int Cin, int Cout, float* bp,
+                        hipStream_t s) {
   const int KD = fused_k(Cout, 1), NP = 32 * feast_fused_nt(Cin);
-  pack_fused_dx_kernel<<<cdiv((int64_t)KD * NP, 256), 256, 0, s>>>(lin_w, u_w, Cin, Cout, KD, NP, bp);
+  pack_fused_dx_kernel<<<cdiv((int64_t)KD * NP + QSELF, 256), 256, 0, s>>>(lin_w, u_w, c, Cin, Cout, KD, NP, bp);
   GEOBI_LAUNCH_OK();
   return 0;
 }
