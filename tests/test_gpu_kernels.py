@@ -166,7 +166,8 @@ def test_feast_conv_random_graph(dev, Cin, Cout, slope, split, fused):
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize('Cout,slope,split', [(32, 0.2, False), (32, 1.0, True), (64, 0.2, True), (128, 0.2, False)])
+@pytest.mark.parametrize('Cout,slope,split', [(32, 0.2, False), (32, 1.0, True), (64, 0.2, True), (128, 0.2, False),
+                                              (128, 1.0, True)])
 def test_feast_rowpass_forms_at_64_channels(dev, Cout, slope, split):
     """The fused backward row pass of a 64-channel layer has three forms (geobi_set_rowpass_form): lane-private row reads,
     rows staged through LDS by global_load_lds (default), and the channel-chunked 32-node-tile kernel (default at
