@@ -513,8 +513,10 @@ def main():
     net = network.DualGNN().to(device)
     flat = FlatParameters(net)            # one flat parameter + one flat gradient bucket
     bucket = flat.bucket
-    # same update rule as the reference's torch.optim.Adam(lr=1e-3) (train_dual.py:162), single-kernel form
-    opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=torch.cuda.is_available())
+    # same update rule as the reference's torch.optim.Adam(lr=1e-3) (train_dual.py:162), one launch over the flat
+    # parameter (train_util.FlatAdam; parity with torch.optim.Adam: tests/test_gpu_model.py)
+    from geobi_gnn_amd.train_util import FlatAdam
+    opt = FlatAdam(flat.parameters(), lr=1e-3) if torch.cuda.is_available() else torch.optim.Adam(flat.parameters(), lr=1e-3)
     dv, df, edges = make_batch(rank, device, args.freq)
 
     log('rank %d: batch resident (%d edges), warming up' % (rank, edges))

@@ -338,6 +338,12 @@ int geobi_row_loss_bwd(const float* a, const float* b, const float* w, const flo
   return row_loss_bwd(a, b, w, gout, n, kind, scale, ga, S(stream));
 }
 
+int geobi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
+  NOTNULL(p); NOTNULL(g); NOTNULL(m); NOTNULL(v);
+  return adam_flat(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, S(stream));
+}
+
 size_t geobi_update_position_ws_bytes(int64_t V, int64_t F) { return update_position_ws_bytes(V, F); }
 int geobi_update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval,
                            const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,

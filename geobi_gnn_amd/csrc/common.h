@@ -277,6 +277,8 @@ int row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int 
                  void* ws, size_t ws_bytes, hipStream_t s);
 int row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
                  float scale, float* ga, hipStream_t s);
+int adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+              float bias_corr1, float bias_corr2, hipStream_t s);
 size_t update_position_ws_bytes(int64_t V, int64_t F);
 int update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval, const float* normals,
                      const float* dd, int64_t V, int64_t F, int n_iter, float* out, void* ws, size_t ws_bytes,

@@ -431,4 +431,44 @@ int head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b
   return 0;
 }
 
+// ---------------------------------------------------------------------------- optimiser step
+// torch.optim.Adam's update (code/train_dual.py:162: the reference's optimiser) over ONE flat parameter vector --
+//   g += wd p;  m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+// -- four floats per thread, the whole chip busy.  torch's own fused form hands one 65 536-element chunk to a workgroup:
+// 15 workgroups for the network's 0.94 M parameters, 45 us per step where this launch takes ~6.
+namespace {
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_bc1,
+                                                        float b1, float b2, float eps, float wd, float rsqrt_bc2) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  auto one = [&](float& pp, float gg, float& mm, float& vv) {
+    gg = wd != 0.f ? fmaf(wd, pp, gg) : gg;
+    mm = fmaf(1.0f - b1, gg - mm, mm);                 // lerp, as torch writes it
+    vv = fmaf(b2, vv, (1.0f - b2) * gg * gg);
+    const float denom = sqrtf(vv) * rsqrt_bc2 + eps;
+    pp -= lr_bc1 * (mm / denom);
+  };
+  if (i + 4 <= n) {
+    float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
+    const float4 G = *reinterpret_cast<const float4*>(g + i);
+    one(P.x, G.x, M.x, V.x); one(P.y, G.y, M.y, V.y); one(P.z, G.z, M.z, V.z); one(P.w, G.w, M.w, V.w);
+    *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = V;
+  } else {
+    for (int64_t k = i; k < n; ++k) one(p[k], g[k], m[k], v[k]);
+  }
+}
+}  // namespace
+
+int adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+              float bias_corr1, float bias_corr2, hipStream_t s) {
+  GEOBI_REQUIRE(n > 0 && bias_corr1 > 0.f && bias_corr2 > 0.f, "adam_flat: n = %lld, bias corrections %g, %g", (long long)n,
+                bias_corr1, bias_corr2);
+  GEOBI_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "adam_flat: 16-byte aligned vectors");
+  adam_flat_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, s>>>(p, g, m, v, n, lr / bias_corr1, b1, b2, eps, wd,
+                                                         1.0f / sqrtf(bias_corr2));
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
 }  // namespace geobi

@@ -251,6 +251,14 @@ int geobi_row_loss_fwd(const float* a, const float* b, const float* w, int64_t n
 int geobi_row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
                        float scale, float* ga, void* stream);
 
+/* ---------------------------------------------------------------- optimiser step ----
+ * torch.optim.Adam's update rule (code/train_dual.py:162, the reference's default optimiser; no amsgrad) over one flat
+ * fp32 vector of n parameters, its gradient and the two moment vectors (16-byte aligned), one launch:
+ *   g += weight_decay p;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;
+ *   p -= lr / bias_corr1 * m / (sqrt(v) / sqrt(bias_corr2) + eps),      bias_corr_k = 1 - beta_k^step (host-side).  */
+int geobi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float bias_corr1, float bias_corr2, void* stream);
+
 /* ---------------------------------------------------------------- vertex update ----
  * data_util.update_position2 (code/data_util.py:529-556; called at code/test_dual.py:63-72 after the
  * network): n_iter Jacobi sweeps  p_v += mean_{f adj v} n_f (n_f . (c_f - p_v)), c_f = face centroid,

@@ -1240,3 +1240,40 @@ def test_tile_geometries_agree_on_the_whole_network(dev):
     assert abs(a[2] - b[2]) < 1e-5 * abs(b[2])
     for k in a[3]:
         assert rel_err(a[3][k], b[3][k]) < _grad_tol(k), k
+
+
+@pytest.mark.parametrize('wd', [0.0, 1e-2])
+def test_flat_adam_matches_torch_adam(dev, wd):
+    """train_util.FlatAdam (one geobi_adam_step launch per tensor) against torch.optim.Adam, the reference's optimiser
+    (train_dual.py:162): ten steps on the same random gradients incl. a vector whose length is not a multiple of 4, a
+    learning-rate change in between (what the schedulers do), then the state dicts swap sides and both continue."""
+    from geobi_gnn_amd.train_util import FlatAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(940_003,), (37, 5)]
+    pa = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FlatAdam(pa, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+
+    def steps(o1, p1, o2, p2, n, seed):
+        gg = torch.Generator().manual_seed(seed)
+        for it in range(n):
+            for x, y in zip(p1, p2):
+                gr = (torch.randn(*x.shape, generator=gg) * (10.0 ** (it % 3 - 1))).to(dev)
+                x.grad = gr.clone(); y.grad = gr.clone()
+            o1.step(); o2.step()
+            if it == n // 2:
+                for o in (o1, o2):
+                    for grp in o.param_groups:
+                        grp['lr'] *= 0.5
+
+    steps(oa, pa, ob, pb, 10, 11)
+    for x, y in zip(pa, pb):
+        assert float((x.detach() - y.detach()).abs().max()) <= 2e-6 * float(y.detach().abs().max())
+    # state dicts are interchangeable: swap them, continue, still equal
+    sa, sb = oa.state_dict(), ob.state_dict()
+    oa2 = FlatAdam(pa, lr=1e-3, weight_decay=wd); oa2.load_state_dict(sb)
+    ob2 = torch.optim.Adam(pb, lr=1e-3, weight_decay=wd); ob2.load_state_dict(sa)
+    steps(oa2, pa, ob2, pb, 4, 12)
+    for x, y in zip(pa, pb):
+        assert float((x.detach() - y.detach()).abs().max()) <= 2e-6 * float(y.detach().abs().max())
