@@ -211,6 +211,8 @@ def loss_n(np, n, norm='L1', fc_p=None, fc=None):
 
 def dual_loss(loss_v, loss_n, v_scale=1, n_scale=1, alpha=None):
     if alpha is None:
+        if v_scale == 1 and n_scale == 1:        # the default: one add, not two multiplications by 1 and an add
+            return loss_v + loss_n
         return loss_v * v_scale + loss_n * n_scale
     return alpha * loss_v * v_scale + (1 - alpha) * loss_n * n_scale
 
