@@ -458,6 +458,7 @@ int net_forward_impl(const geobi_net_params_t* prm, const geobi_level0_t* gv, co
   // vertex head: fc_v2(leaky(fc_v1 .)) -> displacement (or depth along depth_direction) + xyz   (network.py:324-332)
   const int nout_v = P.force_depth ? 1 : 3;
   float* verts = b.take<float>((size_t)V * 3);
+  float* normals = b.take<float>((size_t)F * 3);               // right behind verts: the binding copies both out at once
   float* raw_v = b.take<float>((size_t)V * nout_v);
   float* xf12 = b.take<float>((size_t)F * 12);
   if (!b.ok) return kArenaFull;
@@ -466,7 +467,6 @@ int net_forward_impl(const geobi_net_params_t* prm, const geobi_level0_t* gv, co
   // geometry coupling: x_f = [x_f | centroid | unit normal] of the predicted geometry   (network.py:335-337)
   GEOBI_TRY(face_geom_fwd(verts, fv, x_f, 6, F, xf12, s));
   GEOBI_TRY(gnn_forward(b, Lf, xf12, 12, P.gnn_f, P.pool_mean, &feat_f, out->f, tape ? &tape->f : nullptr, s));
-  float* normals = b.take<float>((size_t)F * 3);
   float* raw_f = b.take<float>((size_t)F * 3);
   if (!b.ok) return kArenaFull;
   GEOBI_TRY(head_fwd(feat_f, 32, F, P.fc_f1_w, P.fc_f1_b, 1024, P.fc_f2_w, P.fc_f2_b, 3, kLeak, 1, nullptr, nullptr, 0,

@@ -173,6 +173,19 @@ def _views(arena, off, n, dtype):
     return arena[off:off + nbytes].view(dtype)
 
 
+def _results(arena, out, V, F):
+    """The two outputs copied out of the arena (which is released / overwritten by the next pass): the library places
+    normals right behind verts, so one copy serves both."""
+    lo, hi = int(out.verts_off), int(out.normals_off) + F * 12
+    if 0 <= int(out.normals_off) - (lo + V * 12) <= 4096:
+        both = arena[lo:hi].clone()
+        verts = both[:V * 12].view(torch.float32).view(V, 3)
+        normals = both[int(out.normals_off) - lo:].view(torch.float32).view(F, 3)
+        return verts, normals
+    return (_views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone(),
+            _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone())
+
+
 def forward(net, data_v, data_f):
     """-> (verts [V,3], normals [F,3]) or None (not covered: the caller runs the module-by-module path).  Sets the
     module-surface side effects of a forward that callers read: PoolingLayer.unpooling_indices / last_clusters."""
@@ -212,8 +225,7 @@ def forward(net, data_v, data_f):
     if rc != 0:
         L.check(rc, 'geobi_net_forward')
     V, F = lv_v.N, lv_f.N
-    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
-    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
+    verts, normals = _results(arena, out, V, F)
     # NOT reproduced: the reference's forward rewrites its input bags (network.py:271,298,337 leave data_v.x /
     # data_f.x as intermediate activations; the module path leaves the l_conv1 outputs there).  No caller of the
     # reference reads them back (train_dual.py:203-208, test_dual.py:21), and copying two [N, 32] activations out of
@@ -333,8 +345,7 @@ def forward_train(net, data_v, data_f):
     V, F = lv_v.N, lv_f.N
     # results are COPIED out (two small tensors): a view would pin the whole training arena (GBs) for as long as the
     # caller keeps the prediction, and the next step's arena could not reuse the block
-    verts = _views(arena, out.verts_off, V * 3, torch.float32).view(V, 3).clone()
-    normals = _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3).clone()
+    verts, normals = _results(arena, out, V, F)
     # the pooling modules' state stays a set of views into this pass' own arena (valid, but the block is held until
     # the next training forward drops them -- before it allocates, see _clear_module_state -- so never two arenas)
     _set_module_state(net, arena, out)

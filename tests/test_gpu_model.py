@@ -641,9 +641,9 @@ def test_executor_side_effects_match_the_module_path(dev):
                 got[(on, train)] = (vp.detach().clone(), npred.detach().clone())
                 if on:
                     assert df.x is df0.x and dv.x is dv0.x                 # bags untouched
-                    # copies: a prediction owns V * 3 / F * 3 floats, not the arena
-                    assert vp.untyped_storage().nbytes() == vp.numel() * 4
-                    assert npred.untyped_storage().nbytes() == npred.numel() * 4
+                    # copies: the two predictions own (V + F) * 3 floats between them (one copy serves both), not the arena
+                    small = (vp.numel() + npred.numel()) * 4 + 4096
+                    assert vp.untyped_storage().nbytes() <= small and npred.untyped_storage().nbytes() <= small
                 else:
                     assert df.x.shape == (df0.x.shape[0], 32) and dv.x.shape == (dv0.x.shape[0], 32)
         executor.ENABLED = True
