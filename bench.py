@@ -46,7 +46,9 @@ FREQ = 32                  # icosphere frequency: F = 20 480 faces
 BATCH = 4
 
 
-def make_batch(rank, device, freq=FREQ, batch=BATCH):
+def make_batch(rank, device, freq=FREQ, batch=BATCH, groups=1):
+    """-> (data_v, data_f) of the 4-mesh union, edges per step, and the same meshes as `groups` unions of batch / groups
+    meshes each (mesh order kept: group k holds meshes k * batch / groups ...)."""
     from geobi_gnn_amd import meshgen
     from geobi_gnn_amd.data import union_batch
     pairs = []
@@ -55,7 +57,23 @@ def make_batch(rank, device, freq=FREQ, batch=BATCH):
         pairs.append(meshgen.synthetic_dual_data(freq, sigma, seed=200 + rank * batch + i))
     edges = sum(p[0].edge_index.shape[1] + p[1].edge_index.shape[1] for p in pairs)
     dv, df = union_batch(pairs)
-    return dv.to(device), df.to(device), edges
+    per = batch // groups
+    parts = []
+    for k in range(groups):
+        sub = pairs[k * per:(k + 1) * per]
+        a, b = union_batch(sub) if len(sub) > 1 else sub[0]
+        parts.append((a.to(device), b.to(device)))
+    return dv.to(device), df.to(device), edges, parts
+
+
+def grouped_step(tg, bucket, opt, collective=True):
+    """The same optimiser step with the batch's meshes as mesh groups in flight together (executor.TrainGroups: the
+    iterations of the reference's accumulation loop, train_dual.py:199-218, overlapped; gradients summed in group order)."""
+    losses = tg.step()
+    if collective:
+        bucket.all_reduce_mean()
+    opt.step()
+    return losses
 
 
 def train_step(net, bucket, opt, dv0, df0, collective=True):
@@ -458,6 +476,8 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--freq', type=int, default=FREQ, help=argparse.SUPPRESS)
+    ap.add_argument('--groups', type=int, default=int(os.environ.get('GEOBI_BENCH_GROUPS', '1')),
+                    help='mesh groups in flight together per step (1: the batch as one union graph on one stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip extra.infer / extra.fresh_batch')
@@ -517,11 +537,21 @@ def main():
     # parameter (train_util.FlatAdam; parity with torch.optim.Adam: tests/test_gpu_model.py)
     from geobi_gnn_amd.train_util import FlatAdam
     opt = FlatAdam(flat.parameters(), lr=1e-3) if torch.cuda.is_available() else torch.optim.Adam(flat.parameters(), lr=1e-3)
-    dv, df, edges = make_batch(rank, device, args.freq)
+    assert args.groups in (1, 2, 4), '--groups: 1, 2 or 4 (the batch has 4 meshes)'
+    dv, df, edges, parts = make_batch(rank, device, args.freq, groups=args.groups)
+    tg = None
+    if args.groups > 1:
+        from geobi_gnn_amd.executor import TrainGroups
+        tg = TrainGroups(net, bucket, 'L1', 'L1').set_groups(parts)
+
+    def one_step():
+        if tg is not None:
+            return grouped_step(tg, bucket, opt)
+        return train_step(net, bucket, opt, dv, df)
 
     log('rank %d: batch resident (%d edges), warming up' % (rank, edges))
     for _ in range(args.warmup):
-        train_step(net, bucket, opt, dv, df)
+        one_step()
 
     def fence():
         torch.cuda.synchronize()
@@ -532,7 +562,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(net, bucket, opt, dv, df)
+        loss = one_step()
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -569,9 +599,10 @@ def main():
                                'corner lists / loss weights built in warm-up and cached per mesh (extra.fresh_batch: '
                                'other meshes every step)' % (args.freq, 20 * args.freq ** 2),
                    'meshes_per_rank': BATCH, 'edges_per_rank_step': edges, 'parallelism': 'dp%d' % world,
+                   'mesh_groups_in_flight': args.groups,
                    'collective': ('none' if world == 1 else
                                   '%s all-reduce of the flat fp32 gradient bucket' % dist.get_backend()),
-                   'final_loss': round(float(loss.item()), 6)},
+                   'final_loss': round(float(loss.sum().item()), 6)},
     }
     if world > 1:
         out['config'].update(mr)

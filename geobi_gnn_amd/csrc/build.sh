@@ -7,6 +7,7 @@ OUT="$HERE/../libgeobi_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
 OBJS=()
+PIDS=()
 mkdir -p "$HERE/build"
 # every header is a dependency of every object (feast_dev.h is shared by feast.hip and feast_fused.hip; a stale
 # object would ship in the in-tree .so), and so is this script (compiler flags)
@@ -18,10 +19,12 @@ for f in capi executor graph gemm feast feast_fused pool geom head_fused meshpre
   for h in "${HDRS[@]}"; do if [ "$h" -nt "$obj" ]; then stale=1; fi; done
   if [ $stale = 1 ]; then
     echo "hipcc $f.hip"
+    rm -f "$obj"                      # a failed compile must not leave the previous object to be linked
     "$HIPCC" $FLAGS -c "$src" -o "$obj" &
+    PIDS+=($!)
   fi
   OBJS+=("$obj")
 done
-wait
+for p in "${PIDS[@]}"; do wait "$p"; done      # set -e: the first failed compile stops the build
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
 echo "built $OUT"

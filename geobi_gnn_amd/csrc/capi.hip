@@ -4,7 +4,9 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -26,8 +28,11 @@ struct ProfRec {
   hipEvent_t a, b;
   double bytes;
   int tag;
+  hipStream_t stream = nullptr;
+  bool closed = false;
 };
-static int g_prof_kernel = PROF_NONE;
+static std::atomic<int> g_prof_kernel{PROF_NONE};
+static std::mutex g_prof_mu;             // the record list is shared by the host threads of a concurrent step
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 
@@ -43,34 +48,47 @@ static hipEvent_t get_event() {
 }
 
 void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag) {
-  if (kernel != g_prof_kernel) return;
+  if (kernel != g_prof_kernel.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.a = get_event();
   r.b = get_event();
   r.bytes = alg_bytes;
   r.tag = tag;
   if (!r.a || !r.b) return;
+  r.stream = s;
   (void)hipEventRecord(r.a, s);
   g_prof.push_back(r);
 }
 
 void prof_end(int kernel, hipStream_t s) {
-  if (kernel != g_prof_kernel || g_prof.empty()) return;
-  (void)hipEventRecord(g_prof.back().b, s);
+  if (kernel != g_prof_kernel.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  // the most recent open record of THIS stream (another thread's record may sit behind it)
+  for (size_t i = g_prof.size(); i-- > 0;) {
+    if (g_prof[i].stream == s && !g_prof[i].closed) {
+      g_prof[i].closed = true;
+      (void)hipEventRecord(g_prof[i].b, s);
+      return;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------- side stream
-static int g_overlap = 1;
-static int g_defer = 0;     // 1: backward calls fork but do not join; the caller joins once (geobi_side_join)
+// Context = host thread.  Everything below the overlap switch is per host thread: a thread drives one stream at a time
+// (the caller's stream of a per-op call; the stream of ONE mesh group in geobi_net_train_groups), so every context has
+// its own side streams and fork / join events and two groups in flight never meet on a shared event.
+static std::atomic<int> g_overlap{[] { const char* e = getenv("GEOBI_OVERLAP"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+static thread_local int g_defer = 0;     // 1: backward calls fork but do not join; the caller joins once (geobi_side_join)
 // Two side streams: [0] at the default priority, [1] at the lowest.  On a big batch the weight-gradient products
 // compete with the backward's own kernels for workgroup slots: at the lowest priority they fill what the main stream
 // leaves free (4.37-4.43 against 4.48-4.57 ms per step on the bench batch).  On small batches -- the host-bound regime,
 // the device has idle gaps anyway -- the low-priority queue is served late and the join at the end waits for it (n = 16:
 // 2.85-2.90 against 2.77-2.79 ms).  side_select() picks per backward; per-op callers get the default one.
-static hipStream_t g_sides[2] = {nullptr, nullptr};
-static int g_side_sel = 0;
-static hipStream_t g_side = nullptr;           // the stream the current / last fork used
-static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
+static thread_local hipStream_t g_sides[2] = {nullptr, nullptr};
+static thread_local int g_side_sel = 0;
+static thread_local hipStream_t g_side = nullptr;           // the stream the current / last fork used
+static thread_local hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
 
 void side_select(int low_priority) {
   static const bool allow = [] { const char* e = getenv("GEOBI_SIDE_PRIORITY"); return !e || atoi(e) != 0; }();
@@ -486,6 +504,7 @@ int geobi_set_overlap(int enable) {
 
 int geobi_prof_enable(int kernel) {
   // returns recorded events to the pool; callers collect before re-enabling
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
   g_prof.clear();
   g_prof_kernel = kernel;
@@ -495,7 +514,9 @@ int geobi_prof_enable(int kernel) {
 int geobi_prof_collect(int tag, int64_t* launches, double* total_ms, double* total_bytes) {
   NOTNULL(launches); NOTNULL(total_ms); NOTNULL(total_bytes);
   *launches = 0; *total_ms = 0.0; *total_bytes = 0.0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
+    if (!r.closed) continue;
     GEOBI_HIP(hipEventSynchronize(r.b));
     if (tag != 0 && r.tag != tag) continue;
     float ms = 0.f;

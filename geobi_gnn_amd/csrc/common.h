@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define GEOBI_H 9    // FeaSt heads on the hot path (network.py:258-268 always passes 9)
 #define GEOBI_HP 12  // row stride (floats) of per-node / per-edge head vectors: 9 padded to 3 x float4
 

@@ -6,9 +6,29 @@
 #include "common.h"
 #include "../../include/geobi_hip.h"
 
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 namespace geobi {
 
 namespace {
+
+// one step of a bounded busy wait (host code: the pause hint exists on x86 only)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+std::atomic<long> g_spin_cap_hits{0};       // size spins that ran into their cap and fell back to the blocking read
 
 constexpr float kLeak = 0.2f;
 constexpr int kRounds = 8;             // net_util.MATCH_ROUNDS
@@ -54,6 +74,7 @@ struct NetTape {
   float *feat_v = nullptr, *feat_f = nullptr, *raw_v = nullptr, *raw_f = nullptr, *verts = nullptr;
   char* arena = nullptr;
   size_t arena_bytes = 0, fwd_peak = 0;
+  int side_low = 0;                       // weight-gradient side stream at the lowest priority whatever the batch size
 };
 
 // Bump allocator over the caller's arena.  Results are taken first, per-call scratch after a mark that is released
@@ -192,7 +213,7 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     // after ~2^26 spins (seconds) the blocking read below takes over whatever happened to the mapped word
     while (!(got = (__atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq))) {
       ++spins;
-      if ((spins & 0x3f) == 0) __builtin_ia32_pause();
+      if ((spins & 0x3f) == 0) cpu_relax();
       if ((spins & 0x3fff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {        // the stream ran dry without a word
         got = __atomic_load_n(&pub[8], __ATOMIC_ACQUIRE) == pub_seq;
         break;
@@ -202,6 +223,9 @@ int pool_layer(Bump& b, const Level& g, const float* x, int C, int pool_mean, Po
     if (got) {
       for (int i = 0; i < 8; ++i) h[i] = vp[i];
     } else {
+      // the mapped word never showed up (or the stream ran dry first): counted, so that a device that stops
+      // publishing degrades to the blocking read VISIBLY (geobi_net_spin_cap_hits) instead of silently stalling
+      if (spins > (1l << 26)) g_spin_cap_hits.fetch_add(1, std::memory_order_relaxed);
       GEOBI_TRY(geobi_read_i32(counters, 8, h, (void*)s));
     }
   }
@@ -567,18 +591,16 @@ extern "C" int geobi_net_release(int64_t handle) {
   return 0;
 }
 
-// Backward of a recorded forward.  g_verts [V,3] / g_normals [F,3] (either may be NULL = zero); `grads` mirrors the
-// parameter struct (same order) and receives (accumulate != 0: is added) the parameter gradients.  corner_segptr /
-// corner_members: vertex -> corner inverse lists of the face table (the geometry coupling's gradient is summed through
-// them in a fixed order).  Scratch is taken from the rest of the forward's arena.
-extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals,
-                                  const geobi_net_params_t* grads, int accumulate, const int32_t* corner_segptr,
-                                  const int32_t* corner_members, void* stream) {
-  NetTape* t = (NetTape*)(intptr_t)handle;
-  if (!t || !grads || !corner_segptr || !corner_members) return set_error("geobi_net_backward: null argument");
-  hipStream_t s = (hipStream_t)stream;
+namespace geobi {
+namespace {
+
+// Backward of a recorded forward from arena offset `start` on (geobi_net_backward: right behind the forward's records;
+// a mesh group of geobi_net_train_groups: behind its loss buffers as well).
+int net_backward_impl(NetTape* t, size_t start, const float* g_verts, const float* g_normals, const geobi_net_params_t* grads,
+                      int accumulate, const int32_t* corner_segptr, const int32_t* corner_members, hipStream_t s) {
+  void* stream = (void*)s;
   Bump b(t->arena, t->arena_bytes);
-  b.off = b.peak = t->fwd_peak;
+  b.off = b.peak = start;
   const geobi_net_params_t& P = t->prm;
   const geobi_net_params_t& G = *grads;
   const int64_t V = t->V, F = t->F;
@@ -604,7 +626,7 @@ extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const fl
   if (zeros) GEOBI_HIP(hipMemsetAsync(zeros, 0, (size_t)(F > V ? F : V) * 3 * sizeof(float), s));
   // weight-gradient GEMMs of every layer run on the side stream and are joined once, at the end; from ~80 k level-0 nodes
   // on (device-bound batches) on the lowest-priority one
-  side_select(V + F >= 80000);
+  side_select(V + F >= 80000 || t->side_low);
   (void)geobi_side_defer(1);
   int rc = head_bwd(t->feat_f, 32, F, P.fc_f1_w, P.fc_f1_b, 1024, P.fc_f2_w, 3, kLeak, 1, nullptr, nullptr, t->raw_f,
                     g_normals ? g_normals : zeros, g_feat_f, (float*)G.fc_f1_w, (float*)G.fc_f1_b, (float*)G.fc_f2_w,
@@ -631,4 +653,223 @@ extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const fl
   rc = geobi_side_join(stream);
   side_select(0);
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------- mesh groups in flight together
+// The reference walks the meshes of a batch one after another (train_dual.py:199-218: forward, loss / batch_size, backward,
+// optimiser step every batch_size meshes).  Meshes are independent units, so the iterations of that loop may run at the same
+// time: each GROUP of meshes (one disjoint-union graph) is a complete forward -> loss -> backward pipeline on its own
+// stream, driven by its own host thread (= its own library context: side streams, events, scan state, size mailbox), with
+// its own arena and its own gradient bucket.  One group's pooling chains (dozens of dependent launches of < 1 workgroup
+// per CU, four host reads) then run under the other groups' FeaSt kernels instead of leaving the chip idle.
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> posted{0}, done{0};
+  std::function<void()> job;
+  bool sleeping = false;
+  void loop() {
+    int seen = 0;
+    for (;;) {
+      long spins = 0;
+      while (posted.load(std::memory_order_acquire) == seen) {
+        if (++spins < 200000) { cpu_relax(); continue; }             // a few ms: the next step of a training loop finds it awake
+        std::unique_lock<std::mutex> lk(mu);
+        sleeping = true;
+        cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen; });
+        sleeping = false;
+      }
+      seen = posted.load(std::memory_order_acquire);
+      job();
+      done.store(seen, std::memory_order_release);
+    }
+  }
+  int post(std::function<void()> j) {
+    job = std::move(j);
+    const int seq = posted.fetch_add(1, std::memory_order_acq_rel) + 1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (sleeping) cv.notify_one();
+    return seq;
+  }
+  void wait(int seq) {
+    long spins = 0;
+    while (done.load(std::memory_order_acquire) != seq)
+      if ((++spins & 0xff) == 0) std::this_thread::yield(); else cpu_relax();
+  }
+};
+// workers live as long as the process (never joined: a static destructor would meet threads parked in the wait)
+std::mutex g_workers_mu;
+std::vector<Worker*>* g_workers = nullptr;
+hipEvent_t g_group_start = nullptr;
+std::vector<hipEvent_t>* g_group_done = nullptr;
+
+struct SrcList { const float* p[GEOBI_MAX_GROUPS]; };
+__global__ void sum_buckets_list_kernel(float* __restrict__ dst, SrcList src, int n_src, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = src.p[0][i];
+  for (int k = 1; k < n_src; ++k) a += src.p[k][i];        // fixed order: the step is bit-reproducible
+  dst[i] = a;
+}
+
+int run_group(const geobi_net_params_t* prm, geobi_train_group_t* g, int kind_v, int kind_n, int device, hipEvent_t start,
+              hipEvent_t done) {
+  GEOBI_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)g->stream;
+  if (start) GEOBI_HIP(hipStreamWaitEvent(s, start, 0));
+  if (g->grad_flat && g->grad_count > 0) GEOBI_HIP(hipMemsetAsync(g->grad_flat, 0, (size_t)g->grad_count * sizeof(float), s));
+  std::unique_ptr<NetTape> tape(new NetTape());
+  tape->prm = *prm;
+  tape->arena = (char*)g->arena; tape->arena_bytes = g->arena_bytes;
+  tape->side_low = 1;                      // with other groups in flight the weight-gradient products always yield
+  Bump b(g->arena, g->arena_bytes);
+  int rc = net_forward_impl(prm, g->gv, g->gf, g->x_v, g->x_f, g->fv, g->depth_direction, g->pos_rev_v, g->pos_rev_f, b,
+                            &g->out, tape.get(), s);
+  g->out.used_bytes = (int64_t)b.peak;
+  if (rc != 0) {
+    if (rc == kArenaFull) set_error("geobi_net_train_groups: arena too small (%zu bytes needed so far, %zu given)", b.peak, g->arena_bytes);
+    return rc;
+  }
+  const int64_t V = tape->V, F = tape->F;
+  // loss (network.py:364-389, dual_loss :392-396) and its gradient with respect to the two predictions
+  float* g_verts = b.take<float>((size_t)V * 3);
+  float* g_normals = b.take<float>((size_t)F * 3);
+  const size_t lws_v = row_loss_ws_bytes(V), lws_f = row_loss_ws_bytes(F);
+  void* ws_lv = b.take<char>(lws_v);
+  void* ws_lf = b.take<char>(lws_f);
+  tape->fwd_peak = b.off;
+  const size_t need = align_up(b.off) + net_backward_bytes(*tape);
+  g->out.used_bytes = (int64_t)need;
+  if (!b.ok || need > g->arena_bytes) {
+    set_error("geobi_net_train_groups: arena too small (%zu bytes needed, %zu given)", need, g->arena_bytes);
+    return kArenaFull;
+  }
+  const float* verts = (const float*)((const char*)g->arena + g->out.verts_off);
+  const float* normals = (const float*)((const char*)g->arena + g->out.normals_off);
+  const float sv = g->w_v ? g->scale_v : g->scale_v / (float)V, sn = g->w_f ? g->scale_n : g->scale_n / (float)F;
+  GEOBI_TRY(row_loss_fwd(verts, g->y_v, g->w_v, V, kind_v, sv, g->losses, ws_lv, lws_v, s));
+  GEOBI_TRY(row_loss_fwd(normals, g->y_f, g->w_f, F, kind_n, sn, g->losses + 1, ws_lf, lws_f, s));
+  GEOBI_TRY(row_loss_bwd(verts, g->y_v, g->w_v, nullptr, V, kind_v, sv, g_verts, s));
+  GEOBI_TRY(row_loss_bwd(normals, g->y_f, g->w_f, nullptr, F, kind_n, sn, g_normals, s));
+  GEOBI_TRY(net_backward_impl(tape.get(), tape->fwd_peak, g_verts, g_normals, &g->grads, 1, g->corner_segptr,
+                              g->corner_members, s));
+  if (done) GEOBI_HIP(hipEventRecord(done, s));
+  return 0;
+}
+
+}  // namespace
+
+}  // namespace geobi
+
+using namespace geobi;
+
+// Backward of a recorded forward.  g_verts [V,3] / g_normals [F,3] (either may be NULL = zero); `grads` mirrors the
+// parameter struct (same order) and receives (accumulate != 0: is added) the parameter gradients.  corner_segptr /
+// corner_members: vertex -> corner inverse lists of the face table (the geometry coupling's gradient is summed through
+// them in a fixed order).  Scratch is taken from the rest of the forward's arena.
+extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals,
+                                  const geobi_net_params_t* grads, int accumulate, const int32_t* corner_segptr,
+                                  const int32_t* corner_members, void* stream) {
+  NetTape* t = (NetTape*)(intptr_t)handle;
+  if (!t || !grads || !corner_segptr || !corner_members) return set_error("geobi_net_backward: null argument");
+  return net_backward_impl(t, t->fwd_peak, g_verts, g_normals, grads, accumulate, corner_segptr, corner_members,
+                           (hipStream_t)stream);
+}
+
+extern "C" size_t geobi_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(geobi_net_params_t);
+    case 1: return sizeof(geobi_level0_t);
+    case 2: return sizeof(geobi_net_out_t);
+    case 3: return sizeof(geobi_train_group_t);
+    case 4: return sizeof(geobi_copy_seg_t);
+    default: return 0;
+  }
+}
+
+extern "C" int geobi_net_spin_cap_hits(void) { return (int)g_spin_cap_hits.load(std::memory_order_relaxed); }
+
+// n_groups complete training pipelines (forward, loss, backward) in flight together, one host thread and one stream each;
+// see the block comment above run_group.  Returns once every group has ENQUEUED all of its work and `main_stream` has
+// been made to wait for all of it (and, with sum_into, has the buckets' fixed-order sum enqueued behind that).
+extern "C" int geobi_net_train_groups(const geobi_net_params_t* prm, geobi_train_group_t* groups, int n_groups,
+                                      int loss_kind_v, int loss_kind_n, float* sum_into, int64_t sum_count,
+                                      void* main_stream) {
+  if (!prm || !groups) return set_error("geobi_net_train_groups: null argument");
+  if (n_groups < 1 || n_groups > GEOBI_MAX_GROUPS) return set_error("geobi_net_train_groups: 1..%d groups", GEOBI_MAX_GROUPS);
+  if ((loss_kind_v != 0 && loss_kind_v != 1) || (loss_kind_n != 0 && loss_kind_n != 1))
+    return set_error("geobi_net_train_groups: loss kinds are 0 (L1) or 1 (L2)");
+  if (prm->force_depth) for (int k = 0; k < n_groups; ++k)
+    if (!groups[k].depth_direction) return set_error("geobi_net_train_groups: force_depth needs depth_direction");
+  for (int k = 0; k < n_groups; ++k) {
+    geobi_train_group_t& g = groups[k];
+    if (!g.gv || !g.gf || !g.pos_rev_v || !g.pos_rev_f || !g.x_v || !g.x_f || !g.fv || !g.y_v || !g.y_f ||
+        !g.corner_segptr || !g.corner_members || !g.arena || !g.losses || !g.stream)
+      return set_error("geobi_net_train_groups: null field in group %d (a group needs its OWN stream, not the null stream)", k);
+    if (sum_into && (!g.grad_flat || g.grad_count != sum_count))
+      return set_error("geobi_net_train_groups: sum_into needs every group's grad_flat with %lld floats", (long long)sum_count);
+    for (int j = 0; j < k; ++j)
+      if (groups[j].stream == g.stream || groups[j].arena == g.arena || (g.grad_flat && groups[j].grad_flat == g.grad_flat))
+        return set_error("geobi_net_train_groups: groups %d and %d share a stream, an arena or a gradient bucket", j, k);
+    g.rc = 0; g.error[0] = 0;
+  }
+  int device = 0;
+  GEOBI_HIP(hipGetDevice(&device));
+  hipStream_t ms = (hipStream_t)main_stream;
+  // one call at a time drives the workers (they are a process-wide resource)
+  std::lock_guard<std::mutex> call_lock(g_workers_mu);
+  if (g_workers == nullptr) { g_workers = new std::vector<Worker*>(); g_group_done = new std::vector<hipEvent_t>(); }
+  while ((int)g_workers->size() < n_groups - 1) {
+    Worker* w = new Worker();
+    w->th = std::thread([w] { w->loop(); });
+    w->th.detach();
+    g_workers->push_back(w);
+  }
+  while ((int)g_group_done->size() < n_groups) {
+    hipEvent_t e;
+    GEOBI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g_group_done->push_back(e);
+  }
+  if (g_group_start == nullptr) GEOBI_HIP(hipEventCreateWithFlags(&g_group_start, hipEventDisableTiming));
+  // the groups read what `main_stream` has produced so far (parameters of the last optimiser step) and must not zero
+  // their buckets before the previous step's sum has read them
+  GEOBI_HIP(hipEventRecord(g_group_start, ms));
+  static const int skew_us = [] { const char* e = getenv("GEOBI_GROUP_SKEW_US"); return e ? atoi(e) : 0; }();
+  const auto call_t0 = std::chrono::steady_clock::now();
+  auto body = [&](int k) {
+    geobi_train_group_t& g = groups[k];
+    if (skew_us > 0 && k > 0) {           // experiment: group k starts k * skew later, so that the groups' phases interleave
+      const auto until = call_t0 + std::chrono::microseconds((long)skew_us * k);
+      while (std::chrono::steady_clock::now() < until) cpu_relax();
+    }
+    g.rc = run_group(prm, &g, loss_kind_v, loss_kind_n, device, g_group_start, (*g_group_done)[k]);
+    if (g.rc != 0) { strncpy(g.error, geobi_last_error(), sizeof(g.error) - 1); g.error[sizeof(g.error) - 1] = 0; }
+  };
+  int seq[GEOBI_MAX_GROUPS];
+  for (int k = 1; k < n_groups; ++k) seq[k] = (*g_workers)[k - 1]->post([&body, k] { body(k); });
+  body(0);
+  for (int k = 1; k < n_groups; ++k) (*g_workers)[k - 1]->wait(seq[k]);
+  int bad = -1;
+  for (int k = 0; k < n_groups; ++k) {
+    if (groups[k].rc == 0) GEOBI_HIP(hipStreamWaitEvent(ms, (*g_group_done)[k], 0));
+    else if (bad < 0) bad = k;
+  }
+  if (bad >= 0) {
+    // a failed group may have left work in flight: the caller's stream waits for all of it before anything is reused
+    for (int k = 0; k < n_groups; ++k)
+      if (groups[k].rc != 0) {
+        hipEvent_t e = (*g_group_done)[k];
+        if (hipEventRecord(e, (hipStream_t)groups[k].stream) == hipSuccess) (void)hipStreamWaitEvent(ms, e, 0);
+      }
+    set_error("geobi_net_train_groups: group %d: %s", bad, groups[bad].error);
+    return groups[bad].rc;
+  }
+  if (sum_into) {
+    SrcList src;
+    for (int k = 0; k < n_groups; ++k) src.p[k] = groups[k].grad_flat;
+    sum_buckets_list_kernel<<<cdiv(sum_count, 256), 256, 0, ms>>>(sum_into, src, n_groups, sum_count);
+    GEOBI_LAUNCH_OK();
+  }
+  return 0;
 }

@@ -1085,7 +1085,7 @@ int launch_one(const float* xa, const float* xb, int Ca, const float* p, const f
   constexpr size_t lds = (size_t)fused_lds_floats<C, MODE, LC, ROWS>() * sizeof(float);
   static_assert(lds <= 163840, "tile exceeds the LDS of a CU");
   static_assert(ROWS == 32 || lds <= 40960, "16-row tiles: four workgroups per CU");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // several host threads may launch (one per mesh group)
   if (!attr_set) {
     GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT, ROWS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1146,7 +1146,7 @@ int launch_rowpass_fused_rt(const float* xa, const float* xb, int Ca, const floa
   constexpr int LDZ = NCT * 32 + 4;
   constexpr size_t lds = ((size_t)RT * (COUT + 4) + (size_t)RT * LDZ + (LC > 0 ? LC * HP : 0)) * sizeof(float);
   static_assert(lds <= 163840, "tiles exceed the LDS of a CU");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // several host threads may launch (one per mesh group)
   if (!attr_set) {
     GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused_kernel<C, LC, COUT, RT, RP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1186,7 +1186,7 @@ int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const floa
                             hipStream_t s) {
   constexpr size_t lds = ((size_t)TN * (COUT + 4) + (size_t)TN * (H * 32 + 4)) * sizeof(float);
   static_assert(lds <= 81920, "two workgroups per CU");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // several host threads may launch (one per mesh group)
   if (!attr_set) {
     GEOBI_HIP(hipFuncSetAttribute((const void*)feast_rowpass_fused128_kernel<COUT, C>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

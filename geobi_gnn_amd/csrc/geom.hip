@@ -216,7 +216,7 @@ __global__ void row_loss_bwd_kernel(const float* __restrict__ a, const float* __
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 3 * n) return;
   float d = a[t] - b[t];
-  float g = gout[0] * scale * (w ? w[t / 3] : 1.0f);
+  float g = (gout ? gout[0] : 1.0f) * scale * (w ? w[t / 3] : 1.0f);       // gout == NULL: the loss is the root
   // torch: d|x|/dx = sign(x) with sign(0) = 0
   ga[t] = kind == 0 ? g * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f)) : g * 2.0f * d;
 }

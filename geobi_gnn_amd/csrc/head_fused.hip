@@ -420,7 +420,7 @@ int head_bwd_fused(const float* x, int64_t N, const float* w1, const float* b1, 
   const int ntiles = cdiv(N, 32);
   constexpr size_t kLds = (size_t)(NCHUNK * 16 * 64 + 3 * HID + HID + HBW * 16 * 32) * sizeof(float);   // 160 KiB
   static_assert(kLds == 163840, "the backward head kernel uses the whole LDS of a CU");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // several host threads may launch (one per mesh group)
   if (!attr_set) {
     GEOBI_HIP(hipFuncSetAttribute((const void*)head_bwd_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kLds));

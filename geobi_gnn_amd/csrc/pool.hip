@@ -1042,10 +1042,11 @@ __global__ __launch_bounds__(256) void lookback_exclusive_scan_kernel(const int*
   }
 }
 
-// persistent look-back state (zeroed once; see the kernel)
-static unsigned long long* g_scan_state = nullptr;
-static int* g_scan_ticket = nullptr;
-static unsigned g_scan_epoch = 0;
+// persistent look-back state (zeroed once; see the kernel).  One per host thread: a thread drives one stream at a time
+// (one mesh group of a concurrent step, executor.hip), so two scans in flight never share state words.
+static thread_local unsigned long long* g_scan_state = nullptr;
+static thread_local int* g_scan_ticket = nullptr;
+static thread_local unsigned g_scan_epoch = 0;
 
 static hipError_t lookback_scan(const int* in, int* out, int64_t n, hipStream_t s) {
   if (g_scan_state == nullptr) {

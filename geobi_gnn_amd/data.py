@@ -162,6 +162,8 @@ class _Concat(object):
 
     def cat(self, parts, adds=None, tail=None, shape=None):
         """parts: contiguous int32 / float32 tensors; adds: per-part int offsets (int32 only); tail: one closing int32."""
+        if parts[0].dtype not in (torch.float32, torch.int32):
+            raise ValueError('union batch: float32 / int32 arrays only (got %s): convert before the collate step' % parts[0].dtype)
         is_float = 1 if parts[0].dtype == torch.float32 else 0
         total = sum(t.numel() for t in parts) + (1 if tail is not None else 0)
         out = torch.empty(total, dtype=parts[0].dtype, device=self.dev)

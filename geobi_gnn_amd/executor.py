@@ -159,8 +159,14 @@ def _level0(data, keep):
 _ARENAS = {}
 
 
+def _arena_key(dev):
+    """Arena and pass generation are per (device, stream): passes on one stream reuse the block in stream order; a pass
+    on ANOTHER stream (a second host thread running its own inference pipeline) gets its own block."""
+    return (dev.type, dev.index, L.stream())
+
+
 def _arena(nbytes, dev):
-    key = (dev.type, dev.index)
+    key = _arena_key(dev)
     a = _ARENAS.get(key)
     if a is None or a.numel() < nbytes:
         _ARENAS[key] = a = None                      # release before growing
@@ -231,7 +237,7 @@ def forward(net, data_v, data_f):
     # reference reads them back (train_dual.py:203-208, test_dual.py:21), and copying two [N, 32] activations out of
     # the arena per pass would cost more than the heads.  The executor leaves data_v.x / data_f.x as given; the
     # coupled facet features [F, 12] of network.py:337 are at `xf_off` of the arena for a caller that wants them.
-    key = (dev.type, dev.index)
+    key = _arena_key(dev)
     _GENERATION[key] = _GENERATION.get(key, 0) + 1
     _set_module_state(net, arena, out, (key, _GENERATION[key]))
     return verts, normals
@@ -375,3 +381,199 @@ def backward(rec, g_verts, g_normals, params):
         return [None] * len(params)
     by_id = {id(p): g for p, g in zip(ordered, grads)}
     return [by_id.get(id(p)) for p in params]
+
+
+# ----------------------------------------------------------------------------------- mesh groups in flight together
+class _Group(ctypes.Structure):
+    """geobi_train_group_t (include/geobi_hip.h)."""
+    _fields_ = [('gv', _F), ('gf', _F), ('pos_rev_v', _F), ('pos_rev_f', _F), ('x_v', _F), ('x_f', _F), ('fv', _F),
+                ('depth_direction', _F), ('y_v', _F), ('y_f', _F), ('w_v', _F), ('w_f', _F),
+                ('scale_v', ctypes.c_float), ('scale_n', ctypes.c_float), ('corner_segptr', _F), ('corner_members', _F),
+                ('arena', _F), ('arena_bytes', ctypes.c_size_t), ('grads', _Params), ('grad_flat', _F),
+                ('grad_count', ctypes.c_int64), ('losses', _F), ('stream', _F), ('out', _Out), ('rc', ctypes.c_int32),
+                ('error', ctypes.c_char * 252)]
+
+
+_KINDS = {'L1': 0, 'L2': 1}
+
+
+class TrainGroups(object):
+    """The meshes of one optimiser step as several GROUPS in flight together (geobi_net_train_groups).
+
+    The reference walks the meshes of a batch one after another -- forward, ``loss / batch_size``, backward, optimiser
+    step every ``batch_size`` meshes (/root/reference/code/train_dual.py:199-218).  Meshes are independent, so the
+    iterations of that loop can overlap: every group (a disjoint-union pair ``(data_v, data_f)`` of one or more meshes)
+    runs forward -> loss -> backward on its own stream, driven by its own host thread inside the library, with its own
+    arena and gradient bucket; the buckets are added up in group order into ``bucket.flat`` (bit-reproducible).  One
+    group's pooling chains and size reads then run under the other groups' FeaSt kernels.
+
+    ``step()`` returns the per-group losses ``[G, 2]`` (each group's SHARE of loss_v / loss_n: they add up to the step's
+    losses as ``parallel.batched_losses`` over the union of all groups gives them) and leaves the summed gradient in
+    ``bucket.flat``; the caller all-reduces and steps the optimiser as after ``loss.backward()``.  Cases outside the
+    executor's fast path run the same step group by group through the module path."""
+
+    def __init__(self, net, bucket, loss_v='L1', loss_n='L1', v_scale=1.0, n_scale=1.0):
+        if loss_v not in _KINDS or loss_n not in _KINDS:
+            raise NotImplementedError('TrainGroups: L1 / L2 losses only (network.loss_v / loss_n)')
+        self.net, self.bucket = net, bucket
+        self.kinds = (loss_v, loss_n)
+        self.scales = (float(v_scale), float(n_scale))
+        self.groups, self._prep, self.losses = [], [], None
+        self.sequential_steps = 0
+        order = _param_order(net)
+        if not all(p.requires_grad for p in order) or len(bucket.params) != len(order):
+            raise L.GeobiError('TrainGroups: every parameter of the network must require a gradient and live in the bucket')
+
+    # ---- per-group resources
+    def _group_bucket(self, dev):
+        """A flat gradient buffer laid out like bucket.flat, and the struct of pointers into it (struct order)."""
+        flat = torch.zeros_like(self.bucket.flat)
+        views, off = {}, 0
+        for p in self.bucket.params:
+            n = p.numel()
+            views[id(p)] = flat[off:off + n]
+            off += n
+        return flat, _pack_pointers([views[id(p)] for p in _param_order(self.net)], self.net)
+
+    def set_groups(self, groups):
+        """groups: list of (data_v, data_f) pairs on the device (each a single mesh or a union batch with mesh_ptr)."""
+        from .network import _fv_index
+        from .parallel import _mesh_weights
+        if not 1 <= len(groups) <= 8:
+            raise ValueError('TrainGroups: 1..8 groups')
+        net = self.net
+        n_mesh = []
+        for dv, df in groups:
+            ptr = getattr(dv, 'mesh_ptr', None)
+            n_mesh.append(1 if ptr is None or ptr.numel() <= 2 else ptr.numel() - 1)
+        total = float(sum(n_mesh))
+        old = self._prep
+        self.groups, self._prep, self._call = list(groups), [], None
+        for k, (dv, df) in enumerate(groups):
+            keep = []
+            lv_v, lv_f = _level0(dv, keep), _level0(df, keep)
+            if lv_v is None or lv_f is None or dv.x.shape[1] != 6 or df.x.shape[1] != 6 or dv.y is None or df.y is None:
+                raise L.GeobiError('TrainGroups: group %d is not a symmetric weighted mesh pair with targets' % k)
+            gv, gf = dv.graph().ensure_in(), df.graph().ensure_in()
+            dev = dv.x.device
+            x_v, x_f = _f32(dv.x, 'data_v.x'), _f32(df.x, 'data_f.x')
+            y_v, y_f = _f32(dv.y, 'data_v.y'), _f32(df.y, 'data_f.y')
+            fv32, corner = _fv_index(df, x_v.shape[0])
+            cidx = corner.get()
+            dd = None
+            if net.force_depth:
+                if getattr(dv, 'depth_direction', None) is None:
+                    raise L.GeobiError('force_depth: data_v.depth_direction is missing')
+                dd = _f32(dv.depth_direction, 'depth_direction')
+            if tuple(y_v.shape) != (x_v.shape[0], 3) or tuple(y_f.shape) != (x_f.shape[0], 3):
+                raise L.GeobiError('TrainGroups: targets must be [V, 3] and [F, 3]')
+            _check_inputs(net, dv, df, fv32, dd, [p.detach() for p in _param_order(net)])
+            w_v, w_f = _mesh_weights(dv), _mesh_weights(df)
+            g = _Group()
+            g.gv, g.gf = ctypes.addressof(lv_v), ctypes.addressof(lv_f)
+            g.pos_rev_v, g.pos_rev_f = gv.pos_in.data_ptr(), gf.pos_in.data_ptr()
+            g.x_v, g.x_f, g.fv = x_v.data_ptr(), x_f.data_ptr(), fv32.data_ptr()
+            g.depth_direction = None if dd is None else dd.data_ptr()
+            g.y_v, g.y_f = y_v.data_ptr(), y_f.data_ptr()
+            g.w_v = None if w_v is None else w_v.data_ptr()
+            g.w_f = None if w_f is None else w_f.data_ptr()
+            share = n_mesh[k] / total
+            g.scale_v, g.scale_n = self.scales[0] * share, self.scales[1] * share
+            g.corner_segptr, g.corner_members = cidx.segptr.data_ptr(), cidx.members.data_ptr()
+            # streams, buckets and arenas are per SLOT and survive a change of meshes
+            res = old[k]['res'] if k < len(old) else None
+            if res is None:
+                flat, gp = self._group_bucket(dev)
+                res = {'stream': torch.cuda.Stream(device=dev), 'flat': flat, 'gp': gp, 'arena': None}
+            shape_key = (lv_v.N, lv_v.E, lv_f.N, lv_f.E)
+            self._prep.append({'g': g, 'keep': keep + [lv_v, lv_f, gv, gf, x_v, x_f, y_v, y_f, fv32, cidx, dd, w_v, w_f],
+                               'res': res, 'shape': shape_key, 'dev': dev})
+        dev = self._prep[0]['dev']
+        if self.losses is None or self.losses.shape[0] != len(groups):
+            self.losses = torch.zeros(len(groups), 2, dtype=torch.float32, device=dev)
+        return self
+
+    def _arena(self, pr, grow=None):
+        res = pr['res']
+        need = grow or _LEARNED_GROUP.get(pr['shape']) or L.size_query('geobi_net_train_arena_bytes', *pr['shape'])
+        if res['arena'] is None or res['arena'].numel() < need:
+            res['arena'] = None
+            res['arena'] = torch.empty(int(need), dtype=torch.uint8, device=pr['dev'])
+        return res['arena']
+
+    def step(self):
+        if not self._prep:
+            raise L.GeobiError('TrainGroups.step: set_groups first')
+        net, n = self.net, len(self._prep)
+        if not (ENABLED and supported(net)):
+            return self._sequential()
+        # the parameter struct and the group array are rebuilt only when a pointer they hold has moved (the flat parameter
+        # of FlatParameters never does): ~100 us of interpreter work per step otherwise, with every group waiting for it
+        order = _param_order(net)
+        sig = (order[0].data_ptr(), order[-1].data_ptr(), self.bucket.flat.data_ptr(),
+               tuple(0 if pr['res']['arena'] is None else pr['res']['arena'].data_ptr() for pr in self._prep))
+        cached = getattr(self, '_call', None)
+        lib = L.lib()
+        for attempt in range(4):
+            if cached is None or cached[0] != sig or attempt > 0:
+                tensors = [_f32(p.detach(), 'parameter') for p in order]
+                prm = _pack_pointers(tensors, net)
+                arr = (_Group * n)()
+                for k, pr in enumerate(self._prep):
+                    g, res = pr['g'], pr['res']
+                    arena = self._arena(pr)
+                    g.arena, g.arena_bytes = arena.data_ptr(), arena.numel()
+                    g.grads, g.grad_flat, g.grad_count = res['gp'], res['flat'].data_ptr(), res['flat'].numel()
+                    g.losses = self.losses.data_ptr() + 8 * k
+                    g.stream = res['stream'].cuda_stream
+                    arr[k] = g
+                sig = sig[:3] + (tuple(pr['res']['arena'].data_ptr() for pr in self._prep),)
+                cached = self._call = (sig, tensors, prm, arr)
+            _, tensors, prm, arr = cached
+            rc = lib.geobi_net_train_groups(ctypes.byref(prm), ctypes.cast(arr, ctypes.c_void_p), n,
+                                            _KINDS[self.kinds[0]], _KINDS[self.kinds[1]], self.bucket.flat.data_ptr(),
+                                            self.bucket.flat.numel(), L.stream())
+            STATS['calls'] += 1
+            if rc != 3:
+                break
+            STATS['arena_retry'] += 1
+            for k, pr in enumerate(self._prep):            # every group reports what it needs
+                if arr[k].rc == 3:
+                    used = int(arr[k].out.used_bytes)
+                    have = pr['res']['arena'].numel()
+                    self._arena(pr, grow=int(1.25 * used) + (64 << 20) if used > have else 2 * have)
+        if rc == 2:
+            STATS['fallback'] += 1
+            return self._sequential()
+        if rc != 0:
+            L.check(rc, 'geobi_net_train_groups')
+        for k, pr in enumerate(self._prep):
+            _LEARNED_GROUP[pr['shape']] = int(1.05 * int(arr[k].out.used_bytes)) + (16 << 20)
+            pr['out'] = arr[k].out
+        return self.losses
+
+    def prediction(self, k):
+        """(verts, normals) of group k from the last step: VIEWS into the group's arena, valid until the next step."""
+        pr = self._prep[k]
+        out, arena = pr['out'], pr['res']['arena']
+        V, F = pr['shape'][0], pr['shape'][2]
+        return (_views(arena, out.verts_off, V * 3, torch.float32).view(V, 3),
+                _views(arena, out.normals_off, F * 3, torch.float32).view(F, 3))
+
+    def _sequential(self):
+        """The same step group by group through the network's autograd node (module path or single-stream executor)."""
+        from .parallel import batched_losses
+        self.sequential_steps += 1
+        self.bucket.zero()
+        rows = []
+        for pr, (dv, df) in zip(self._prep, self.groups):
+            vp, npred, _ = self.net((dv.shallow_copy(), df.shallow_copy()))
+            lv, ln = batched_losses(vp, npred, dv, df, self.kinds[0], self.kinds[1])
+            lv, ln = lv * float(pr['g'].scale_v), ln * float(pr['g'].scale_n)
+            (lv + ln).backward()
+            rows.append(torch.stack([lv.detach(), ln.detach()]))
+        self.losses = torch.stack(rows)
+        return self.losses
+
+
+_LEARNED_GROUP = {}

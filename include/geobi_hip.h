@@ -10,8 +10,9 @@
  *   - every pointer is a BORROWED device pointer (HBM) unless marked `host`; the library never
  *     allocates, frees or synchronises: scratch comes in through `ws` / `ws_bytes` (query the size
  *     with the matching *_ws_bytes function, which is a pure host computation + rocPRIM size query).
- *     Two documented exceptions: geobi_read_i32 (the size read-back: waits for `stream`) and
- *     geobi_patch_grow_host (an ordered traversal over HOST arrays)
+ *     Three documented exceptions: geobi_read_i32 (the size read-back: waits for `stream`), the whole-network
+ *     entry points geobi_net_forward / geobi_net_forward_train / geobi_net_train_groups (four reads of pooling sizes
+ *     per pass, through mapped host memory) and geobi_patch_grow_host (an ordered traversal over HOST arrays)
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
  *   - return value 0 = ok, non-zero = error; the message is in geobi_last_error() (thread-local)
  *   - node features are row-major fp32; indices inside the library are int32 (max 2^31-1 edges);
@@ -406,6 +407,55 @@ int geobi_net_forward_train(const geobi_net_params_t* prm, const geobi_level0_t*
 int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals, const geobi_net_params_t* grads,
                        int accumulate, const int32_t* corner_segptr, const int32_t* corner_members, void* stream);
 int geobi_net_release(int64_t handle);
+/* how often a pooling-size wait ran into its spin cap and fell back to the blocking read (diagnostic; 0 on a healthy run) */
+int geobi_net_spin_cap_hits(void);
+
+/* Several mesh groups of one optimiser step in flight together.  The reference walks the meshes of a batch one after
+ * another (code/train_dual.py:199-218: forward, loss / batch_size, backward; optimiser step every batch_size meshes);
+ * meshes are independent, so the iterations may overlap.  Each group (a disjoint-union graph of one or more meshes) is a
+ * complete forward -> loss -> backward pipeline -- geobi_net_forward_train, the losses of code/network.py:364-396
+ * (loss kinds 0 = L1, 1 = L2) and geobi_net_backward -- on its OWN stream with its OWN arena and gradient buffers, driven by
+ * its own host thread inside the library (group 0 by the calling thread), so that one group's pooling chains and size
+ * reads run under the other groups' FeaSt kernels.  Per-context state of the library (side streams, events, scan state)
+ * is per host thread, so the groups share nothing but the read-only parameters.
+ *   w_v / w_f       per-row loss weights (a union of meshes: 1 / (meshes in the group * rows of the row's mesh)); NULL: 1 / rows
+ *   scale_v/scale_n factor on the group's two losses: dual_loss's v_scale / n_scale times (meshes in the group / meshes in
+ *                   the step), so that the group losses ADD UP to the step's loss and the gradients to its gradient
+ *   grads           where the group's 72 parameter gradients are ADDED; when they are views of one flat buffer, name it in
+ *                   grad_flat / grad_count and the call zeroes it first (on the group's stream)
+ *   losses          device float[2]: the group's share of loss_v and loss_n
+ *   out, rc, error  filled per group (out as geobi_net_forward_train; out.used_bytes = the arena bytes this group needs)
+ * Ordering: every group stream first waits for what `main_stream` holds at the call; on return `main_stream` waits for
+ * every group, and, with sum_into != NULL, sum_into[i] = grad_flat_0[i] + grad_flat_1[i] + ... (fixed order: the step is
+ * bit-reproducible) is enqueued on it.  The call returns when everything is ENQUEUED.  Return: 0, or the code of the first
+ * failed group (GEOBI_NET_FALLBACK / GEOBI_NET_ARENA as for geobi_net_forward_train; the caller repeats the whole call). */
+#define GEOBI_MAX_GROUPS 8
+typedef struct {
+  const geobi_level0_t *gv, *gf;
+  const int32_t *pos_rev_v, *pos_rev_f;
+  const float *x_v, *x_f;
+  const int32_t* fv;
+  const float* depth_direction;
+  const float *y_v, *y_f;
+  const float *w_v, *w_f;
+  float scale_v, scale_n;
+  const int32_t *corner_segptr, *corner_members;
+  void* arena;
+  size_t arena_bytes;
+  geobi_net_params_t grads;
+  float* grad_flat;
+  int64_t grad_count;
+  float* losses;
+  void* stream;
+  geobi_net_out_t out;
+  int32_t rc;
+  char error[252];
+} geobi_train_group_t;
+/* sizeof of a struct of this header as the library was compiled (which: 0 geobi_net_params_t, 1 geobi_level0_t,
+ * 2 geobi_net_out_t, 3 geobi_train_group_t, 4 geobi_copy_seg_t; else 0): a binding checks its mirror against it */
+size_t geobi_abi_sizeof(int which);
+int geobi_net_train_groups(const geobi_net_params_t* prm, geobi_train_group_t* groups, int n_groups, int loss_kind_v,
+                           int loss_kind_n, float* sum_into, int64_t sum_count, void* main_stream);
 
 /* ---------------------------------------------------------------- concurrency --------------
  * Weight-gradient GEMMs are off the critical path of a backward call; by default they run on a

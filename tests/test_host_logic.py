@@ -498,3 +498,26 @@ def test_optimizers_eval_means_and_checkpoint_keys(tmp_path):
     assert list(sd.keys()) == list(ora.state_dict().keys())
     ora.load_state_dict(sd, strict=True)
     assert torch.equal(ora.fc_f2.weight, net.fc_f2.weight.detach())
+
+
+def test_struct_mirrors_match_the_library_layout():
+    """The ctypes mirrors of the header's structs have the size the library was compiled with (a drift would corrupt
+    every call that passes one; geobi_abi_sizeof)."""
+    import ctypes
+    from geobi_gnn_amd import _lib as L, executor, data
+    lib = L.lib()
+    mirrors = {0: executor._Params, 1: executor._Level0, 2: executor._Out, 3: executor._Group, 4: data._CopySeg}
+    for which, cls in mirrors.items():
+        assert lib.geobi_abi_sizeof(which) == ctypes.sizeof(cls), (which, cls.__name__)
+    assert lib.geobi_abi_sizeof(99) == 0
+
+
+def test_union_batch_graphs_refuses_other_dtypes():
+    """a float64 / int64 part must raise in the collate step, not be copied as 4-byte words."""
+    import pytest
+    from geobi_gnn_amd.data import _Concat
+    cc = _Concat(torch.device('cpu'))
+    with pytest.raises(ValueError):
+        cc.cat([torch.zeros(4, dtype=torch.float64)])
+    with pytest.raises(ValueError):
+        cc.cat([torch.zeros(4, dtype=torch.int64)])
