@@ -79,6 +79,7 @@ void prof_end(int kernel, hipStream_t s) {
 // (the caller's stream of a per-op call; the stream of ONE mesh group in geobi_net_train_groups), so every context has
 // its own side streams and fork / join events and two groups in flight never meet on a shared event.
 static std::atomic<int> g_overlap{[] { const char* e = getenv("GEOBI_OVERLAP"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+static thread_local int g_overlap_here = -1;   // this context's override of g_overlap (-1: none); side_override()
 static thread_local int g_defer = 0;     // 1: backward calls fork but do not join; the caller joins once (geobi_side_join)
 // Two side streams: [0] at the default priority, [1] at the lowest.  On a big batch the weight-gradient products
 // compete with the backward's own kernels for workgroup slots: at the lowest priority they fill what the main stream
@@ -95,9 +96,11 @@ void side_select(int low_priority) {
   g_side_sel = (low_priority && allow) ? 1 : 0;
 }
 
+void side_override(int mode) { g_overlap_here = mode; }
+
 Fork fork_side_stream(hipStream_t main) {
   Fork f;
-  if (!g_overlap) return f;
+  if (g_overlap_here == 0 || (g_overlap_here < 0 && !g_overlap)) return f;
   if (g_sides[g_side_sel] == nullptr) {
     int lo = 0, hi = 0;
     if (g_side_sel == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
@@ -141,6 +144,18 @@ using namespace geobi;
     if ((p) == nullptr) return set_error("%s: %s is NULL", __func__, #p); \
   } while (0)
 
+// Size limits of the header (GEOBI_MAX_NODES / GEOBI_MAX_EDGES): every entry point that takes a node or edge count
+// rejects what is above them, so that no kernel ever forms a 32-bit element index beyond its range.
+static int sizes_ok(const char* fn, int64_t nodes, int64_t edges) {
+  if (nodes < 0 || edges < 0) return set_error("%s: negative size (%lld nodes, %lld edges)", fn, (long long)nodes, (long long)edges);
+  if (nodes > GEOBI_MAX_NODES)
+    return set_error("%s: %lld nodes exceed GEOBI_MAX_NODES = %d per call (split the mesh into patches)", fn, (long long)nodes, GEOBI_MAX_NODES);
+  if (edges > GEOBI_MAX_EDGES)
+    return set_error("%s: %lld edges exceed GEOBI_MAX_EDGES = %d per call (split the mesh into patches)", fn, (long long)edges, GEOBI_MAX_EDGES);
+  return 0;
+}
+#define SIZES(nodes, edges) GEOBI_TRY(sizes_ok(__func__, (int64_t)(nodes), (int64_t)(edges)))
+
 extern "C" {
 
 int geobi_version(void) { return 100; }
@@ -151,6 +166,7 @@ size_t geobi_csr_ws_bytes(int64_t E, int64_t N) { return csr_ws_bytes(E, N); }
 int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_t N, int drop_self,
                        int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* bad, void* ws, size_t ws_bytes,
                        void* stream) {
+  SIZES(N, E);
   NOTNULL(rowptr);
   if (E > 0) { NOTNULL(seg); NOTNULL(nbr); NOTNULL(col); NOTNULL(eid); }
   return csr_from_coo(seg, nbr, E, N, drop_self, rowptr, col, eid, bad, ws, ws_bytes, S(stream));
@@ -158,6 +174,7 @@ int geobi_csr_from_coo(const int64_t* seg, const int64_t* nbr, int64_t E, int64_
 
 int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t Ecap, int32_t* rowptr_t,
                         int32_t* col_t, int32_t* pos_t, int32_t* inv_pos, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, Ecap);
   NOTNULL(rowptr); NOTNULL(rowptr_t);
   if (Ecap > 0) { NOTNULL(col); NOTNULL(col_t); NOTNULL(pos_t); }
   return csr_transpose(rowptr, col, N, Ecap, rowptr_t, col_t, pos_t, inv_pos, ws, ws_bytes, S(stream));
@@ -165,11 +182,13 @@ int geobi_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t N, in
 
 int geobi_csr_reverse_index(const int32_t* rowptr, const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* pos_rev, int32_t* flag, void* stream) {
+  SIZES(0, E);
   NOTNULL(rowptr);                         // flag may be NULL: the caller knows the graph is symmetric
   if (E > 0) { NOTNULL(row); NOTNULL(col); NOTNULL(pos_rev); }
   return csr_reverse_index(rowptr, row, col, E, pos_rev, flag, S(stream));
 }
 int geobi_expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, void* stream) {
+  SIZES(N, 0);
   return expand_rowptr(rowptr, N, row, S(stream));
 }
 int geobi_concat32(const geobi_copy_seg_t* segs, int n_segs, int is_float, void* stream) {
@@ -180,6 +199,7 @@ int geobi_concat32(const geobi_copy_seg_t* segs, int n_segs, int is_float, void*
   return concat32(reinterpret_cast<const CopySeg*>(segs), n_segs, is_float, S(stream));
 }
 int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream) {
+  SIZES(0, n);
   return gather_f32(src, idx, n, dst, S(stream));
 }
 
@@ -199,6 +219,7 @@ int geobi_feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const int32_t* rowptr_in, const int32_t* col_in, const float* lin_w, const float* u_w,
                     const float* c, const float* bias, int Cout, float slope, float* out, float* p, float* z,
                     float* wf, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, E);
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c); NOTNULL(bias);
   NOTNULL(out); NOTNULL(p);
   if (Cb > 0) NOTNULL(xb);
@@ -216,6 +237,7 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
                     const float* c, int Cout, float slope, const float* out, const float* gout, const float* p,
                     const float* z, const float* wf, float* dxa, float* dxb, float* dlin_w, float* du_w, float* dc,
                     float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, E);
   NOTNULL(xa); NOTNULL(rowptr_in); NOTNULL(rowptr_out); NOTNULL(lin_w); NOTNULL(u_w); NOTNULL(c);
   NOTNULL(gout); NOTNULL(p); NOTNULL(dlin_w); NOTNULL(du_w); NOTNULL(dc); NOTNULL(dbias);
   if (slope != 1.0f) NOTNULL(out);
@@ -229,6 +251,7 @@ int geobi_feast_bwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N,
 
 int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,
                           int64_t E, float* w_out, void* stream) {
+  SIZES(0, E);
   if (E > 0) { NOTNULL(x); NOTNULL(row); NOTNULL(col); NOTNULL(w_out); }
   return edge_weight_t10(x, C, row, col, w_in, E, w_out, S(stream));
 }
@@ -236,6 +259,7 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
 size_t geobi_match_ws_bytes(int64_t N) { return match_ws_bytes(N); }
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, 0);
   NOTNULL(rowptr); NOTNULL(cluster); NOTNULL(status);
   return match_heavy_edge(rowptr, col, w, N, rounds, init, cluster, cluster_final, status, ws, ws_bytes, S(stream));
 }
@@ -248,6 +272,7 @@ size_t geobi_match_coarsen_ws_bytes(int64_t N) { return match_coarsen_ws_bytes(N
 int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,
                         int32_t* state, int32_t* cluster_final, int32_t* cnew, int32_t* segptr, int32_t* members,
                         int32_t* counters, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, 0);
   NOTNULL(rowptr); NOTNULL(state); NOTNULL(cluster_final); NOTNULL(cnew); NOTNULL(segptr);     // col: NULL when E = 0
   NOTNULL(members); NOTNULL(counters); NOTNULL(ws);
   return match_coarsen(rowptr, col, w, N, rounds, init, state, cluster_final, cnew, segptr, members, counters, ws,
@@ -257,6 +282,7 @@ int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* 
 size_t geobi_relabel_ws_bytes(int64_t N) { return relabel_ws_bytes(N); }
 int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, int32_t* cnew, int32_t* count,
                           void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, 0);
   NOTNULL(cluster); NOTNULL(cnew); NOTNULL(count);
   return relabel_compact(cluster, N, rep_is_self, cnew, count, ws, ws_bytes, S(stream));
 }
@@ -264,39 +290,47 @@ int geobi_relabel_compact(const int32_t* cluster, int64_t N, int rep_is_self, in
 size_t geobi_segment_csr_ws_bytes(int64_t n) { return segment_csr_ws_bytes(n); }
 int geobi_segment_csr(const int32_t* seg, int64_t n, int64_t nseg, int32_t* segptr, int32_t* members, void* ws,
                       size_t ws_bytes, void* stream) {
+  SIZES(nseg, n);          // n counts list entries (3 F corners of a face table): an edge-like count
   NOTNULL(segptr);
   return segment_csr(seg, n, nseg, segptr, members, ws, ws_bytes, S(stream));
 }
 size_t geobi_segment_pairs_ws_bytes(int64_t nseg) { return segment_pairs_ws_bytes(nseg); }
 int geobi_segment_csr_pairs(const int32_t* cnew, const int32_t* raw, int64_t N, int64_t nseg, int32_t* segptr,
                             int32_t* members, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(N, 0);
   NOTNULL(cnew); NOTNULL(raw); NOTNULL(segptr); NOTNULL(members);
   return segment_csr_pairs(cnew, raw, N, nseg, segptr, members, ws, ws_bytes, S(stream));
 }
 int geobi_segment_csr_compose(const int32_t* segptr1, const int32_t* members1, const int32_t* segptr2,
                               const int32_t* members2, int64_t nseg2, int64_t n_fine, int32_t* segptr12,
                               int32_t* members12, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(n_fine, 0);
   NOTNULL(segptr1); NOTNULL(members1); NOTNULL(segptr2); NOTNULL(members2); NOTNULL(segptr12); NOTNULL(members12);
   return segment_csr_compose(segptr1, members1, segptr2, members2, nseg2, n_fine, segptr12, members12, ws, ws_bytes,
                              S(stream));
 }
 int geobi_segment_max_fwd(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg,
                           float* out, int32_t* arg, void* stream) {
+  SIZES(nseg, 0);
   return segment_max_fwd(x, C, segptr, members, nseg, out, arg, S(stream));
 }
 int geobi_segment_max_bwd(const float* gout, const int32_t* arg, const int32_t* seg, int C, int64_t nseg,
                           int64_t n_fine, float* gx, void* stream) {
+  SIZES(n_fine, 0);
   return segment_max_bwd(gout, arg, seg, C, nseg, n_fine, gx, S(stream));
 }
 int geobi_segment_sum(const float* x, int C, const int32_t* segptr, const int32_t* members, int64_t nseg, int mean,
                       float* out, void* stream) {
+  SIZES(nseg, 0);
   return segment_sum(x, C, segptr, members, nseg, mean, out, S(stream));
 }
 int geobi_segment_mean_bwd(const float* gout, const int32_t* seg, const int32_t* segptr, int C, int64_t n_fine,
                            float* gx, void* stream) {
+  SIZES(n_fine, 0);
   return segment_mean_bwd(gout, seg, segptr, C, n_fine, gx, S(stream));
 }
 int geobi_gather_rows(const float* x, const int32_t* idx, int C, int64_t n_out, float* out, void* stream) {
+  SIZES(n_out, 0);
   return gather_rows(x, idx, C, n_out, out, S(stream));
 }
 size_t geobi_pool_edge_rows_ws_bytes(int64_t nbound) { return pool_edge_rows_ws_bytes(nbound); }
@@ -304,6 +338,7 @@ int geobi_pool_edge_rows(const int32_t* cnew, const int32_t* segptr, const int32
                          const int32_t* col, const float* w, const int32_t* ncount, int64_t nbound,
                          int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
                          int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(nbound, 0);
   NOTNULL(cnew); NOTNULL(segptr); NOTNULL(members); NOTNULL(rowptr); NOTNULL(ncount); NOTNULL(rowptr_c);
   NOTNULL(row_c); NOTNULL(col_c); NOTNULL(count); NOTNULL(overflow);
   return pool_edge_rows(cnew, segptr, members, rowptr, col, w, ncount, nbound, rowptr_c, row_c, col_c, w_c, count,
@@ -313,22 +348,26 @@ size_t geobi_pool_edge_ws_bytes(int64_t E) { return pool_edge_ws_bytes(E); }
 int geobi_pool_edge(const int32_t* cnew, const int32_t* row, const int32_t* col, const float* w, int64_t E,
                     int64_t nmax, int32_t* rowptr_c, int32_t* row_c, int32_t* col_c, float* w_c, int32_t* count,
                     void* ws, size_t ws_bytes, void* stream) {
+  SIZES(nmax, E);
   NOTNULL(cnew); NOTNULL(rowptr_c); NOTNULL(count);
   return pool_edge(cnew, row, col, w, E, nmax, rowptr_c, row_c, col_c, w_c, count, ws, ws_bytes, S(stream));
 }
 
 int geobi_face_geom_fwd(const float* verts, const int32_t* fv, const float* xf, int ldxf, int64_t F, float* out,
                         void* stream) {
+  SIZES(F, 0);
   return face_geom_fwd(verts, fv, xf, ldxf, F, out, S(stream));
 }
 int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout, int64_t F, float* corner_grad,
                         void* stream) {
+  SIZES(F, 0);
   return face_geom_bwd(verts, fv, gout, F, corner_grad, S(stream));
 }
 
 int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
                    int ld_resid, float* h, float* raw, float* out, void* stream) {
+  SIZES(N, 0);
   NOTNULL(x); NOTNULL(w1); NOTNULL(b1); NOTNULL(w2); NOTNULL(b2); NOTNULL(raw); NOTNULL(out);
   if (mode == 0) NOTNULL(resid);
   return head_fwd(x, Cin, N, w1, b1, K, w2, b2, nout, slope, mode, dd, resid, ld_resid, h, raw, out, S(stream));
@@ -338,6 +377,7 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const fl
                    int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,
                    float* dx, float* dw1, float* db1, float* dw2, float* db2, int accumulate, void* ws,
                    size_t ws_bytes, void* stream) {
+  SIZES(N, 0);
   NOTNULL(x); NOTNULL(w1); NOTNULL(w2); NOTNULL(raw); NOTNULL(gout);
   NOTNULL(dw1); NOTNULL(db1); NOTNULL(dw2); NOTNULL(db2);
   return head_bwd(x, Cin, N, w1, b1, K, w2, nout, slope, mode, dd, h, raw, gout, dx, dw1, db1, dw2, db2, accumulate, ws,
@@ -347,11 +387,13 @@ int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const fl
 size_t geobi_row_loss_ws_bytes(int64_t n) { return row_loss_ws_bytes(n); }
 int geobi_row_loss_fwd(const float* a, const float* b, const float* w, int64_t n, int kind, float scale, float* out,
                        void* ws, size_t ws_bytes, void* stream) {
+  SIZES(n, 0);
   NOTNULL(a); NOTNULL(b); NOTNULL(out);
   return row_loss_fwd(a, b, w, n, kind, scale, out, ws, ws_bytes, S(stream));
 }
 int geobi_row_loss_bwd(const float* a, const float* b, const float* w, const float* gout, int64_t n, int kind,
                        float scale, float* ga, void* stream) {
+  SIZES(n, 0);
   NOTNULL(a); NOTNULL(b); NOTNULL(gout); NOTNULL(ga);
   return row_loss_bwd(a, b, w, gout, n, kind, scale, ga, S(stream));
 }
@@ -366,6 +408,7 @@ size_t geobi_update_position_ws_bytes(int64_t V, int64_t F) { return update_posi
 int geobi_update_position2(const float* points, const int32_t* fv, const int32_t* vf, int maxval,
                            const float* normals, const float* dd, int64_t V, int64_t F, int n_iter, float* out,
                            void* ws, size_t ws_bytes, void* stream) {
+  SIZES(V > F ? V : F, 0);
   NOTNULL(points); NOTNULL(fv); NOTNULL(vf); NOTNULL(normals); NOTNULL(out);
   return update_position2(points, fv, vf, maxval, normals, dd, V, F, n_iter, out, ws, ws_bytes, S(stream));
 }
@@ -374,22 +417,26 @@ size_t geobi_vertex_faces_ws_bytes(int64_t F, int64_t V) { return vertex_faces_w
 
 int geobi_vertex_faces(const int32_t* fv, int64_t F, int64_t V, int32_t* rowptr, int32_t* list, void* ws,
                        size_t ws_bytes, void* stream) {
+  SIZES(F > V ? F : V, 0);
   NOTNULL(fv); NOTNULL(rowptr); NOTNULL(list); NOTNULL(ws);
   return vertex_faces(fv, F, V, rowptr, list, ws, ws_bytes, S(stream));
 }
 
 int geobi_vf_padded(const int32_t* rowptr, const int32_t* list, int64_t V, int maxval, int32_t* vf, void* stream) {
+  SIZES(V, 0);
   NOTNULL(rowptr); NOTNULL(list); NOTNULL(vf);
   return vf_padded(rowptr, list, V, maxval, vf, S(stream));
 }
 
 int geobi_max_degree(const int32_t* rowptr, int64_t N, int32_t* out, void* stream) {
+  SIZES(N, 0);
   NOTNULL(rowptr); NOTNULL(out);
   return max_degree(rowptr, N, out, S(stream));
 }
 
 int geobi_mesh_normals(const float* points, const int32_t* fv, int64_t F, int64_t V, const int32_t* rowptr,
                        const int32_t* list, float* fnormal, float* centroid, float* vnormal, void* stream) {
+  SIZES(F > V ? F : V, 0);
   NOTNULL(points); NOTNULL(fv); NOTNULL(fnormal); NOTNULL(centroid);
   if (vnormal != nullptr) { NOTNULL(rowptr); NOTNULL(list); }
   return mesh_normals(points, fv, F, V, rowptr, list, fnormal, centroid, vnormal, S(stream));
@@ -399,12 +446,14 @@ size_t geobi_ring_graph_ws_bytes(int64_t n_nodes) { return ring_graph_ws_bytes(n
 
 int geobi_ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
                            int64_t n_nodes, int32_t* rowptr_g, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(n_nodes, 0);
   NOTNULL(fv); NOTNULL(rowptr_vf); NOTNULL(list); NOTNULL(rowptr_g); NOTNULL(ws);
   return ring_graph_count(kind, fv, rowptr_vf, list, n_nodes, rowptr_g, ws, ws_bytes, S(stream));
 }
 
 int geobi_ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
                           int64_t n_nodes, const int32_t* rowptr_g, int32_t* col, void* stream) {
+  SIZES(n_nodes, 0);
   NOTNULL(fv); NOTNULL(rowptr_vf); NOTNULL(list); NOTNULL(rowptr_g); NOTNULL(col);
   return ring_graph_fill(kind, fv, rowptr_vf, list, n_nodes, rowptr_g, col, S(stream));
 }
@@ -413,6 +462,7 @@ size_t geobi_calc_weight_ws_bytes(void) { return calc_weight_ws_bytes(); }
 
 int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                       int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(0, E);
   NOTNULL(pos); NOTNULL(ws);
   if (E > 0) { NOTNULL(row); NOTNULL(col); }
   if (w != nullptr) NOTNULL(normal);
@@ -429,18 +479,21 @@ size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V) { return submesh_ws_byte
 
 int geobi_submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
                   int32_t* count, void* ws, size_t ws_bytes, void* stream) {
+  SIZES(V > n_sel ? V : n_sel, 0);
   NOTNULL(fv); NOTNULL(sel); NOTNULL(v_idx); NOTNULL(f_sub); NOTNULL(count); NOTNULL(ws);
   return submesh(fv, sel, n_sel, V, v_idx, f_sub, count, ws, ws_bytes, S(stream));
 }
 
 int geobi_patch_accumulate(const float* vert_p, const float* norm_p, const int32_t* v_idx, const int32_t* f_idx,
                            int64_t nv, int64_t nf, float* Vp, float* Np, int32_t* sum_v, void* stream) {
+  SIZES(nv > nf ? nv : nf, 0);
   NOTNULL(vert_p); NOTNULL(norm_p); NOTNULL(v_idx); NOTNULL(f_idx); NOTNULL(Vp); NOTNULL(Np); NOTNULL(sum_v);
   return patch_accumulate(vert_p, norm_p, v_idx, f_idx, nv, nf, Vp, Np, sum_v, S(stream));
 }
 
 int geobi_patch_finalize(float* Vp, float* Np, const int32_t* sum_v, int64_t V, int64_t F, float scale, float cx,
                          float cy, float cz, void* stream) {
+  SIZES(V > F ? V : F, 0);
   NOTNULL(Vp); NOTNULL(Np); NOTNULL(sum_v);
   return patch_finalize(Vp, Np, sum_v, V, F, scale, cx, cy, cz, S(stream));
 }

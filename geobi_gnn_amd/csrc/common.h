@@ -60,6 +60,7 @@ struct Fork {
   hipStream_t side = nullptr;   // nullptr: overlap disabled, run on the caller's stream
   hipEvent_t join = nullptr;
 };
+void side_override(int mode);                  // this host thread: 0 = no side stream, 1 = side stream, -1 = the process-wide setting
 void side_select(int low_priority);            // which side stream the next forks use (default / lowest priority)
 Fork fork_side_stream(hipStream_t main);       // side stream waits for everything enqueued on `main` so far
 int join_side_stream(const Fork& f, hipStream_t main);   // `main` waits for the side stream

@@ -527,6 +527,10 @@ extern "C" int geobi_net_forward(const geobi_net_params_t* prm, const geobi_leve
                                  void* arena, size_t arena_bytes, geobi_net_out_t* out, void* stream) {
   if (!prm || !gv || !gf || !x_v || !x_f || !fv || !arena || !out) return set_error("geobi_net_forward: null argument");
   if (prm->force_depth && !depth_direction) return set_error("geobi_net_forward: force_depth needs depth_direction");
+  if (gv->N > GEOBI_MAX_NODES || gf->N > GEOBI_MAX_NODES || gv->E > GEOBI_MAX_EDGES || gf->E > GEOBI_MAX_EDGES || gv->N < 0 ||
+      gf->N < 0 || gv->E < 0 || gf->E < 0)
+    return set_error("geobi_net_forward: level-0 sizes outside [0, GEOBI_MAX_NODES = %d] nodes / [0, GEOBI_MAX_EDGES = %d] edges (split the mesh into patches)",
+                     GEOBI_MAX_NODES, GEOBI_MAX_EDGES);
   Bump b(arena, arena_bytes);
   int rc = net_forward_impl(prm, gv, gf, x_v, x_f, fv, depth_direction, nullptr, nullptr, b, out, nullptr, (hipStream_t)stream);
   out->used_bytes = (int64_t)b.peak;
@@ -561,6 +565,10 @@ extern "C" int geobi_net_forward_train(const geobi_net_params_t* prm, const geob
   if (!prm || !gv || !gf || !pos_rev_v || !pos_rev_f || !x_v || !x_f || !fv || !arena || !out || !handle)
     return set_error("geobi_net_forward_train: null argument");
   if (prm->force_depth && !depth_direction) return set_error("geobi_net_forward_train: force_depth needs depth_direction");
+  if (gv->N > GEOBI_MAX_NODES || gf->N > GEOBI_MAX_NODES || gv->E > GEOBI_MAX_EDGES || gf->E > GEOBI_MAX_EDGES || gv->N < 0 ||
+      gf->N < 0 || gv->E < 0 || gf->E < 0)
+    return set_error("geobi_net_forward_train: level-0 sizes outside [0, GEOBI_MAX_NODES = %d] nodes / [0, GEOBI_MAX_EDGES = %d] edges (split the mesh into patches)",
+                     GEOBI_MAX_NODES, GEOBI_MAX_EDGES);
   NetTape* tape = new NetTape();
   tape->prm = *prm;
   tape->arena = (char*)arena; tape->arena_bytes = arena_bytes;
@@ -713,16 +721,25 @@ __global__ void sum_buckets_list_kernel(float* __restrict__ dst, SrcList src, in
   dst[i] = a;
 }
 
+struct SideOverride {          // scoped: the weight-gradient products of a group stay on the group's own stream
+  explicit SideOverride(int mode) { side_override(mode); }
+  ~SideOverride() { side_override(-1); }
+};
+
 int run_group(const geobi_net_params_t* prm, geobi_train_group_t* g, int kind_v, int kind_n, int device, hipEvent_t start,
-              hipEvent_t done) {
+              hipEvent_t done, int n_groups) {
   GEOBI_HIP(hipSetDevice(device));
+  // With several groups in flight the other groups ARE the concurrent work: a side stream per group on top of that measured
+  // slower (same box, alternating, bench batch as 2 groups: 4.13-4.25 ms per step without, 4.29-4.56 with side streams at
+  // the default priority, 5.6-5.9 at the lowest -- the join at the end of a backward then waits for starved products).
+  static const int side_in_groups = [] { const char* e = getenv("GEOBI_GROUP_SIDE"); return e ? atoi(e) : 0; }();
+  SideOverride scoped(n_groups > 1 && !side_in_groups ? 0 : -1);
   hipStream_t s = (hipStream_t)g->stream;
   if (start) GEOBI_HIP(hipStreamWaitEvent(s, start, 0));
   if (g->grad_flat && g->grad_count > 0) GEOBI_HIP(hipMemsetAsync(g->grad_flat, 0, (size_t)g->grad_count * sizeof(float), s));
   std::unique_ptr<NetTape> tape(new NetTape());
   tape->prm = *prm;
   tape->arena = (char*)g->arena; tape->arena_bytes = g->arena_bytes;
-  tape->side_low = 1;                      // with other groups in flight the weight-gradient products always yield
   Bump b(g->arena, g->arena_bytes);
   int rc = net_forward_impl(prm, g->gv, g->gf, g->x_v, g->x_f, g->fv, g->depth_direction, g->pos_rev_v, g->pos_rev_f, b,
                             &g->out, tape.get(), s);
@@ -807,6 +824,9 @@ extern "C" int geobi_net_train_groups(const geobi_net_params_t* prm, geobi_train
     if (!g.gv || !g.gf || !g.pos_rev_v || !g.pos_rev_f || !g.x_v || !g.x_f || !g.fv || !g.y_v || !g.y_f ||
         !g.corner_segptr || !g.corner_members || !g.arena || !g.losses || !g.stream)
       return set_error("geobi_net_train_groups: null field in group %d (a group needs its OWN stream, not the null stream)", k);
+    if (g.gv->N > GEOBI_MAX_NODES || g.gf->N > GEOBI_MAX_NODES || g.gv->E > GEOBI_MAX_EDGES || g.gf->E > GEOBI_MAX_EDGES ||
+        g.gv->N < 0 || g.gf->N < 0 || g.gv->E < 0 || g.gf->E < 0)
+      return set_error("geobi_net_train_groups: group %d: level-0 sizes outside GEOBI_MAX_NODES / GEOBI_MAX_EDGES", k);
     if (sum_into && (!g.grad_flat || g.grad_count != sum_count))
       return set_error("geobi_net_train_groups: sum_into needs every group's grad_flat with %lld floats", (long long)sum_count);
     for (int j = 0; j < k; ++j)
@@ -843,7 +863,7 @@ extern "C" int geobi_net_train_groups(const geobi_net_params_t* prm, geobi_train
       const auto until = call_t0 + std::chrono::microseconds((long)skew_us * k);
       while (std::chrono::steady_clock::now() < until) cpu_relax();
     }
-    g.rc = run_group(prm, &g, loss_kind_v, loss_kind_n, device, g_group_start, (*g_group_done)[k]);
+    g.rc = run_group(prm, &g, loss_kind_v, loss_kind_n, device, g_group_start, (*g_group_done)[k], n_groups);
     if (g.rc != 0) { strncpy(g.error, geobi_last_error(), sizeof(g.error) - 1); g.error[sizeof(g.error) - 1] = 0; }
   };
   int seq[GEOBI_MAX_GROUPS];

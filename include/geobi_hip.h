@@ -15,8 +15,13 @@
  *     per pass, through mapped host memory) and geobi_patch_grow_host (an ordered traversal over HOST arrays)
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
  *   - return value 0 = ok, non-zero = error; the message is in geobi_last_error() (thread-local)
- *   - node features are row-major fp32; indices inside the library are int32 (max 2^31-1 edges);
- *     the reference's int64 COO `edge_index` is accepted by geobi_csr_from_coo
+ *   - node features are row-major fp32; indices inside the library are int32.  Per call and graph level at most
+ *     GEOBI_MAX_NODES nodes (rows of any per-node array, faces and vertices alike) and GEOBI_MAX_EDGES edges: below
+ *     these every 32-bit element index a kernel forms -- node x channels (<= 128), node x 16 lanes, edge x 16 lanes --
+ *     stays under 2^31 / 2^32; byte and float offsets into per-node / per-edge rows are 64-bit throughout.  Larger
+ *     sizes are REJECTED by the entry points (error code, message), never truncated.  The path's largest
+ *     configuration (a 150 k-face scan: 1.97 M edges) is 1 % of the limits; bigger meshes go through the patch split.
+ *     The reference's int64 COO `edge_index` is accepted by geobi_csr_from_coo
  *   - FeaSt heads are fixed at 9 (every FeaStConv on the path is built with heads=9,
  *     code/network.py:258-268); per-node / per-edge head vectors use a padded row stride of
  *     GEOBI_HEAD_STRIDE floats
@@ -33,6 +38,8 @@ extern "C" {
 
 #define GEOBI_HEADS 9
 #define GEOBI_HEAD_STRIDE 12
+#define GEOBI_MAX_NODES ((1 << 24) - 1)  /* 16 777 215 */
+#define GEOBI_MAX_EDGES ((1 << 28) - 1)  /* 268 435 455 */
 
 int geobi_version(void);
 const char* geobi_last_error(void);

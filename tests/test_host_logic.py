@@ -521,3 +521,33 @@ def test_union_batch_graphs_refuses_other_dtypes():
         cc.cat([torch.zeros(4, dtype=torch.float64)])
     with pytest.raises(ValueError):
         cc.cat([torch.zeros(4, dtype=torch.int64)])
+
+
+def test_sizes_beyond_the_documented_limits_are_rejected():
+    """include/geobi_hip.h: GEOBI_MAX_NODES / GEOBI_MAX_EDGES.  An entry point returns an error for a larger call before
+    anything touches the device (so this runs without a GPU) -- never a truncated 32-bit index inside a kernel."""
+    import ctypes
+    from geobi_gnn_amd import _lib as L
+    lib = L.lib()
+    max_nodes, max_edges = (1 << 24) - 1, (1 << 28) - 1
+    one = ctypes.c_void_p(256)                     # never dereferenced: the size check comes first
+    rc = lib.geobi_feast_fwd(one, None, 32, 0, max_nodes + 1, 10, one, one, one, one, one, one, 32, 1.0, one, one, None, None,
+                             one, 0, None)
+    assert rc != 0 and b'GEOBI_MAX_NODES' in lib.geobi_last_error()
+    rc = lib.geobi_feast_fwd(one, None, 32, 0, 10, max_edges + 1, one, one, one, one, one, one, 32, 1.0, one, one, None, None,
+                             one, 0, None)
+    assert rc != 0 and b'GEOBI_MAX_EDGES' in lib.geobi_last_error()
+    rc = lib.geobi_segment_sum(one, 32, one, one, max_nodes + 1, 0, one, None)
+    assert rc != 0 and b'GEOBI_MAX_NODES' in lib.geobi_last_error()
+    rc = lib.geobi_edge_weight_t10(one, 32, one, one, one, -1, one, None)
+    assert rc != 0 and b'negative' in lib.geobi_last_error()
+
+    class _L0(ctypes.Structure):
+        _fields_ = [('N', ctypes.c_int64), ('E', ctypes.c_int64), ('rowptr', ctypes.c_void_p), ('col', ctypes.c_void_p),
+                    ('row', ctypes.c_void_p), ('weight', ctypes.c_void_p)]
+    from geobi_gnn_amd import executor
+    big, ok = _L0(max_nodes + 1, 10, 256, 256, 256, 256), _L0(10, 10, 256, 256, 256, 256)
+    prm, out = executor._Params(), executor._Out()
+    rc = lib.geobi_net_forward(ctypes.byref(prm), ctypes.byref(big), ctypes.byref(ok), one, one, one, None, one, 1 << 20,
+                               ctypes.byref(out), None)
+    assert rc != 0 and b'GEOBI_MAX_NODES' in lib.geobi_last_error()

@@ -5,6 +5,9 @@ set -euo pipefail
 NAME=$1; UNIT=$2; shift 2
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../geobi_gnn_amd/csrc" && pwd)"
 mkdir -p "$HERE/build/variants"
+# the other objects must match the tree the variant is compiled from: build.sh recompiles whatever is older than a header
+# (round 3: a variant linked against stale objects is one of the two candidate causes of the kp_g1 fault)
+bash "$HERE/build.sh" > /dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function "$@" -c "$HERE/$UNIT.hip" -o "$HERE/build/variants/${UNIT}_$NAME.o" 2>&1 | grep -E "error|Spill: [1-9]" || true
 OBJS=()
 for f in capi executor graph gemm feast feast_fused pool geom head_fused meshprep patch; do
