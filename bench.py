@@ -25,6 +25,10 @@ extra     rank 0 at N = 1, after the timed region (never part of `value`):
           fresh_batch  ms/step when every step unions 4 OTHER pre-processed meshes from a pool of 12 (what a loader
                        hands over, train_dual.py:199-201): the union is built inside each step (two launches:
                        every array is a shifted concatenation of per-mesh arrays); plus the one-off per-mesh build
+          test_list    BASELINE configs[1] as the reference runs it (test_dual.py:90-148): the 29-mesh stand-in list through
+                       patches.predict_mesh (preprocessing, patch split at 20 000 faces, network, merge, vertex update):
+                       total ms, meshes/s, M-edges/s, number of patch-split meshes, share of time outside the network
+          mesh_groups  the timed step with the batch as 2 mesh groups in flight together (geobi_net_train_groups)
 N > 1     `config.collective_us` (the gradient all-reduce alone, HIP events), `config.rank_ms_per_step` (min / max).
 """
 import argparse
@@ -84,11 +88,32 @@ def train_step(net, bucket, opt, dv0, df0, collective=True):
     vp, npred, _ = net((dv, df))
     lv, ln = batched_losses(vp, npred, dv0, df0, 'L1', 'L1')
     loss = network.dual_loss(lv, ln)
+    split = collective and SPLIT_ALLREDUCE is not None
+    if split:
+        from geobi_gnn_amd import executor
+        executor.FACET_EVENTS = SPLIT_ALLREDUCE['events']
     loss.backward()
-    if collective:
+    if split:
+        executor.FACET_EVENTS = None
+        bucket.all_reduce_mean_split(SPLIT_ALLREDUCE['offset'], SPLIT_ALLREDUCE['events'], SPLIT_ALLREDUCE['stream'])
+    elif collective:
         bucket.all_reduce_mean()
     opt.step()
     return loss
+
+
+# GEOBI_SPLIT_ALLREDUCE=1 at N > 1: the facet half of the bucket is all-reduced under the vertex branch's backward
+# (parallel.GradBucket.all_reduce_mean_split); built and checked for equality with the one-shot form (gloo tests), NOT
+# measured -- RCCL only runs in the driver's multi-GPU tier.  Off by default.
+SPLIT_ALLREDUCE = None
+
+
+def enable_split_allreduce(net, bucket, device):
+    global SPLIT_ALLREDUCE
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    for e in evs:
+        e.record()                              # creates the underlying hipEvent_t (torch does so lazily)
+    SPLIT_ALLREDUCE = {'events': evs, 'offset': bucket.facet_offset(net), 'stream': torch.cuda.Stream(device=device)}
 
 
 def measure_roofline(net, bucket, opt, dv, df, steps=3):
@@ -291,6 +316,70 @@ def measure_fresh_batch(net, bucket, opt, device, freq, pool_size=12, steps=12, 
                                'indices and vertex -> corner lists, one-off per mesh'}
 
 
+def measure_test_list(net, device, sub_size=20000):
+    """BASELINE configs[1] as the reference runs it (test_dual.py:90-148, predict_dir): EVERY mesh of the test list
+    through the whole chain -- preprocessing, patch split above `sub_size` faces, network, overlap merge, 60-sweep vertex
+    update, the two angular errors.  The Synthetic test set is an external download: SURVEY 8d's stand-in list, 29 noisy
+    icospheres (one per name of dataset/Synthetic/test_list.txt), n from {16, 22, 32, 45} x 3 noise levels, seeds 100 + i;
+    the n = 45 meshes (40 500 faces) are patch-split.  Raw meshes resident in HBM; weights = the bench's (random init + the
+    timed steps), so the angles say nothing -- tools/test_synthetic.py reports them for a trained network."""
+    from geobi_gnn_amd import meshgen, patches
+    freqs, sigmas = (16, 22, 32, 45), (0.1, 0.2, 0.3)
+    meshes = []
+    for i in range(29):
+        noisy, clean, faces = meshgen.noisy_icosphere(freqs[i % 4], sigmas[i % 3], seed=100 + i)
+        meshes.append((torch.as_tensor(noisy, dtype=torch.float32, device=device),
+                       torch.as_tensor(faces, dtype=torch.int32, device=device),
+                       torch.as_tensor(clean, dtype=torch.float32, device=device)))
+    edges = sum(16 * f.shape[0] + p.shape[0] - 60 for p, f, _ in meshes)       # E_v0 + E_f0 = (3F + V) + (13F - 60)
+
+    def run(stats=None):
+        split = 0
+        for pts, fv, gt in meshes:
+            r = patches.predict_mesh(net, pts, fv, sub_size=sub_size, n_iter=60, gt_points=gt, stats=stats)
+            split += r['n_patches'] > 1
+        return split
+    run()                                                                    # warm-up (arenas, first launches)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        n_split = run()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    stats = {}
+    run(stats)                                                               # one more pass with a sync behind every phase
+    tot = sum(stats.values())
+    log('test list: %.1f ms for 29 meshes (%d patch-split), %.1f M-edges/s' % (dt * 1e3, n_split, edges / dt / 1e6))
+    return {'workload': 'Synthetic test_list stand-in: 29 noisy icospheres n in {16,22,32,45} x 3 noise levels through '
+                        'patches.predict_mesh (preprocessing, patch split at %d faces, network, merge, 60-sweep vertex '
+                        'update, angular errors), raw meshes resident in HBM' % sub_size,
+            'total_ms': round(dt * 1e3, 2), 'meshes_per_s': round(29 / dt, 1), 'M_edges_per_s': round(edges / dt / 1e6, 1),
+            'level0_edges': edges, 'faces': sum(f.shape[0] for _, f, _ in meshes), 'patch_split_meshes': n_split,
+            'share_outside_network': round(1.0 - stats.get('network', 0.0) / tot, 3),
+            'phase_ms_synchronised': {k: round(v * 1e3, 2) for k, v in stats.items()},
+            'phase_note': 'one extra pass with a device sync behind every phase: upper bounds of the overlapped costs'}
+
+
+def measure_groups(net, bucket, opt, parts_by_groups, steps=20, warm=5):
+    """The timed step again with the batch's 4 meshes as mesh groups in flight together (executor.TrainGroups:
+    geobi_net_train_groups), same box, right after the headline measurement: ms per step for 2 groups of 2 meshes."""
+    from geobi_gnn_amd.executor import TrainGroups
+    out = {}
+    for g, parts in parts_by_groups.items():
+        tg = TrainGroups(net, bucket, 'L1', 'L1').set_groups(parts)
+        for _ in range(warm):
+            grouped_step(tg, bucket, opt, collective=False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            grouped_step(tg, bucket, opt, collective=False)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        out['groups_%d' % g] = {'ms_per_step': round(dt * 1e3, 3), 'sequential_fallbacks': tg.sequential_steps}
+        log('mesh groups %d: %.3f ms/step' % (g, dt * 1e3))
+    out['note'] = ('same batch, same step (forward, loss, backward, Adam; no collective), the meshes as G groups on G '
+                   'streams / host threads, gradient buckets summed in group order; the headline value above is the '
+                   'single-union step (--groups 1)')
+    return out
+
+
 def measure_collective(bucket, before=None, after=None, steps=5):
     """N > 1: the gradient all-reduce alone, in steps of their own after the timed region: `before()` refills the
     bucket (forward + backward), then bucket.all_reduce_mean() is bracketed by HIP events on the compute stream
@@ -393,7 +482,7 @@ def pmc_mfma():
             for k, v in ks.items() if k.endswith('(all instantiations)')}
 
 
-def cpu_baseline(freq=FREQ, timed=5, warm=2):
+def cpu_baseline(freq=FREQ, timed=3, warm=1):
     """PyG-shaped oracle, fp32, all host cores, ONE mesh of the bench size (bounded sample)."""
     from geobi_gnn_amd import meshgen
     from oracle import ref_model as R, pyg_ops as P
@@ -538,6 +627,8 @@ def main():
     from geobi_gnn_amd.train_util import FlatAdam
     opt = FlatAdam(flat.parameters(), lr=1e-3) if torch.cuda.is_available() else torch.optim.Adam(flat.parameters(), lr=1e-3)
     assert args.groups in (1, 2, 4), '--groups: 1, 2 or 4 (the batch has 4 meshes)'
+    if world > 1 and os.environ.get('GEOBI_SPLIT_ALLREDUCE') == '1':
+        enable_split_allreduce(net, bucket, device)
     dv, df, edges, parts = make_batch(rank, device, args.freq, groups=args.groups)
     tg = None
     if args.groups > 1:
@@ -599,7 +690,7 @@ def main():
                                'corner lists / loss weights built in warm-up and cached per mesh (extra.fresh_batch: '
                                'other meshes every step)' % (args.freq, 20 * args.freq ** 2),
                    'meshes_per_rank': BATCH, 'edges_per_rank_step': edges, 'parallelism': 'dp%d' % world,
-                   'mesh_groups_in_flight': args.groups,
+                   'mesh_groups_in_flight': args.groups, 'split_allreduce': SPLIT_ALLREDUCE is not None,
                    'collective': ('none' if world == 1 else
                                   '%s all-reduce of the flat fp32 gradient bucket' % dist.get_backend()),
                    'final_loss': round(float(loss.sum().item()), 6)},
@@ -615,7 +706,11 @@ def main():
             out['roofline_mfma'] = measure_mfma(net, bucket, opt, dv, df)
         if world == 1 and not args.no_extra:
             out['extra'] = {'infer': measure_infer(net, device),
-                            'fresh_batch': measure_fresh_batch(net, bucket, opt, device, args.freq)}
+                            'fresh_batch': measure_fresh_batch(net, bucket, opt, device, args.freq),
+                            'test_list': measure_test_list(net, device)}
+            if args.groups == 1:
+                _, _, _, parts2 = make_batch(rank, device, args.freq, groups=2)
+                out['extra']['mesh_groups'] = measure_groups(net, bucket, opt, {2: parts2})
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.freq)
     if world > 1:

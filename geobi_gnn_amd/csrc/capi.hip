@@ -97,6 +97,7 @@ void side_select(int low_priority) {
 }
 
 void side_override(int mode) { g_overlap_here = mode; }
+hipStream_t side_current() { return g_side; }
 
 Fork fork_side_stream(hipStream_t main) {
   Fork f;
@@ -104,7 +105,8 @@ Fork fork_side_stream(hipStream_t main) {
   if (g_sides[g_side_sel] == nullptr) {
     int lo = 0, hi = 0;
     if (g_side_sel == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (hipStreamCreateWithPriority(&g_sides[g_side_sel], hipStreamNonBlocking, lo) != hipSuccess) {
+    const hipError_t ce = hipStreamCreateWithPriority(&g_sides[g_side_sel], hipStreamNonBlocking, lo);
+    if (ce != hipSuccess) {
       g_sides[g_side_sel] = nullptr;
       return f;
     }
@@ -201,6 +203,11 @@ int geobi_concat32(const geobi_copy_seg_t* segs, int n_segs, int is_float, void*
 int geobi_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, void* stream) {
   SIZES(0, n);
   return gather_f32(src, idx, n, dst, S(stream));
+}
+
+int geobi_debug_exp_le0(const float* x, float* y, int64_t n, void* stream) {
+  NOTNULL(x); NOTNULL(y);
+  return exp_le0_probe(x, y, n, S(stream));
 }
 
 size_t geobi_feast_wpack_floats(int Cin, int Cout) { return feast_wpack_floats(Cin, Cout); }
@@ -469,10 +476,40 @@ int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row,
   return calc_weight(pos, normal, row, col, E, extra_zero_edges, w, mean_len, ws, ws_bytes, S(stream));
 }
 
-int geobi_patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F,
-                          int64_t seed, int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n) {
-  NOTNULL(fv); NOTNULL(vf_rowptr); NOTNULL(vf_list); NOTNULL(out); NOTNULL(out_n);
-  return patch_grow_host(fv, vf_rowptr, vf_list, F, seed, neighbor_count, ring_count, out, out_n);
+size_t geobi_patch_grow_state_ints(int64_t F, int64_t V) { return patch_grow_state_ints(F, V); }
+
+int geobi_patch_grow_init(int32_t* state, int64_t F, int64_t V, const float* d2, void* stream) {
+  SIZES(F > V ? F : V, 0);
+  NOTNULL(state); NOTNULL(d2);
+  return patch_grow_init(state, F, V, d2, S(stream));
+}
+
+int geobi_patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F, int64_t V, const float* d2, int64_t seed,
+                     int64_t neighbor_count, int64_t ring_count, int patch_id, int32_t* state, int32_t* sel_out,
+                     int32_t* n_out, int32_t* mailbox, int pick_next, void* stream) {
+  SIZES(F > V ? F : V, 0);
+  NOTNULL(fv); NOTNULL(vf); NOTNULL(state); NOTNULL(sel_out);
+  return patch_grow(fv, vf, maxval, F, V, d2, seed, neighbor_count, ring_count, patch_id, state, sel_out, n_out, mailbox,
+                    pick_next, S(stream));
+}
+
+// Mapped host memory a kernel can hand small results over through (patch sizes): `n` int32 slots, zeroed, valid until the
+// next call from the same host thread asks for more.
+int geobi_host_mailbox(int n, int32_t** host_ptr) {
+  NOTNULL(host_ptr);
+  GEOBI_REQUIRE(n > 0 && n <= (1 << 20), "geobi_host_mailbox: 1 .. 2^20 slots");
+  static thread_local int32_t* box = nullptr;
+  static thread_local int cap = 0;
+  if (n > cap) {
+    if (box) (void)hipHostFree(box);
+    box = nullptr; cap = 0;
+    const int want = n < 1024 ? 1024 : n;
+    GEOBI_HIP(hipHostMalloc((void**)&box, (size_t)want * sizeof(int32_t), hipHostMallocMapped | hipHostMallocPortable));
+    cap = want;
+  }
+  for (int i = 0; i < n; ++i) box[i] = 0;
+  *host_ptr = box;
+  return 0;
 }
 
 size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V) { return submesh_ws_bytes(n_sel, V); }

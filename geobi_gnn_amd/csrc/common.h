@@ -61,6 +61,7 @@ struct Fork {
   hipEvent_t join = nullptr;
 };
 void side_override(int mode);                  // this host thread: 0 = no side stream, 1 = side stream, -1 = the process-wide setting
+hipStream_t side_current();                    // the side stream this thread's last fork used (nullptr: none yet)
 void side_select(int low_priority);            // which side stream the next forks use (default / lowest priority)
 Fork fork_side_stream(hipStream_t main);       // side stream waits for everything enqueued on `main` so far
 int join_side_stream(const Fork& f, hipStream_t main);   // `main` waits for the side stream
@@ -169,6 +170,7 @@ size_t colsum_ws_bytes(int64_t M, int J);
 int colsum(const float* A, int lda, int64_t M, int J, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 
 // feast.hip
+int exp_le0_probe(const float* x, float* y, int64_t n, hipStream_t s);
 int feast_ldz(int Cin);
 size_t feast_fwd_ws_bytes(int64_t N, int Cin, int Cout);
 int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64_t E, const int32_t* rowptr_in,
@@ -255,8 +257,11 @@ size_t calc_weight_ws_bytes();
 int calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                 int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, hipStream_t s);
 // patch.hip (patch split / merge for large meshes)
-int patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F, int64_t seed,
-                    int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n);
+size_t patch_grow_state_ints(int64_t F, int64_t V);
+int patch_grow_init(int32_t* state, int64_t F, int64_t V, const float* d2, hipStream_t s);
+int patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F, int64_t V, const float* d2, int64_t seed,
+               int64_t neighbor_count, int64_t ring_count, int patch_id, int32_t* state, int32_t* sel_out, int32_t* n_out,
+               int32_t* mailbox, int pick_next, hipStream_t s);
 size_t submesh_ws_bytes(int64_t n_sel, int64_t V);
 int submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
             int32_t* count, void* ws, size_t ws_bytes, hipStream_t s);

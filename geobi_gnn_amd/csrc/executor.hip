@@ -602,6 +602,9 @@ extern "C" int geobi_net_release(int64_t handle) {
 namespace geobi {
 namespace {
 
+// geobi_net_backward_facet_events: where the NEXT backward of this host thread marks "the facet branch's gradients are final"
+thread_local hipEvent_t g_facet_ev_main = nullptr, g_facet_ev_side = nullptr;
+
 // Backward of a recorded forward from arena offset `start` on (geobi_net_backward: right behind the forward's records;
 // a mesh group of geobi_net_train_groups: behind its loss buffers as well).
 int net_backward_impl(NetTape* t, size_t start, const float* g_verts, const float* g_normals, const geobi_net_params_t* grads,
@@ -642,6 +645,16 @@ int net_backward_impl(NetTape* t, size_t start, const float* g_verts, const floa
   if (rc) return fail(rc);
   rc = gnn_backward(b, t->f, G.gnn_f, g_feat_f, g_xf12, accumulate, s);
   if (rc) return fail(rc);
+  if (g_facet_ev_main) {
+    // every gradient of gnn_f / fc_f1 / fc_f2 is enqueued by now: the main stream's share up to here, the weight-gradient
+    // products on the side stream.  A data-parallel caller starts the all-reduce of that half of the bucket behind these
+    // two events, i.e. UNDER the vertex branch's backward ("overlap with backward tail").
+    hipEvent_t em = g_facet_ev_main, es = g_facet_ev_side;
+    g_facet_ev_main = g_facet_ev_side = nullptr;
+    if (hipEventRecord(em, s) != hipSuccess) return fail(set_error("geobi_net_backward: facet event"));
+    hipStream_t side = side_current();
+    if (es && hipEventRecord(es, side ? side : s) != hipSuccess) return fail(set_error("geobi_net_backward: facet event"));
+  }
   // geometry coupling: d[x_f | centroid | normal] -> per-corner gradients -> vertices (fixed-order segment sum)
   rc = face_geom_bwd(t->verts, t->fv, g_xf12, F, corner, s);
   if (rc) return fail(rc);
@@ -792,6 +805,12 @@ extern "C" int geobi_net_backward(int64_t handle, const float* g_verts, const fl
   if (!t || !grads || !corner_segptr || !corner_members) return set_error("geobi_net_backward: null argument");
   return net_backward_impl(t, t->fwd_peak, g_verts, g_normals, grads, accumulate, corner_segptr, corner_members,
                            (hipStream_t)stream);
+}
+
+extern "C" int geobi_net_backward_facet_events(void* ev_main, void* ev_side) {
+  g_facet_ev_main = (hipEvent_t)ev_main;
+  g_facet_ev_side = (hipEvent_t)ev_side;
+  return 0;
 }
 
 extern "C" size_t geobi_abi_sizeof(int which) {

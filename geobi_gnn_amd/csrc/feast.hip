@@ -494,6 +494,12 @@ __global__ void feast_du_final_kernel(const float* __restrict__ partial, int blo
   *dst = accumulate ? *dst + s : s;
 }
 
+// diagnostic: the softmax's exp alone (tests/test_gpu_kernels.py checks it against fp64)
+__global__ void exp_le0_probe_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = exp_le0(x[i]);
+}
+
 // ------------------------------------------------------------------------- small helpers
 __global__ void pack_wf_kernel(const float* __restrict__ lin_w, int Cin, int Cout, int Kp, float* __restrict__ wf) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,6 +669,13 @@ int launch_logits(int C, const float* xa, const float* xb, int Ca, const float* 
 }
 
 }  // namespace
+
+int exp_le0_probe(const float* x, float* y, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  exp_le0_probe_kernel<<<cdiv(n, 256), 256, 0, s>>>(x, y, n);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
 
 int feast_ldz(int Cin) { return (H * Cin + 3) / 4 * 4; }
 int feast_ldr(int Cout) { return H * Cout + 2 * HP; }   // [r | dp(12) | dcs(12)]

@@ -3,10 +3,9 @@
 //   /root/reference/code/data_util.py:55-84          mesh_get_neighbor_np: face-ring growth from a seed
 //   /root/reference/code/data_util.py:318-336        get_submesh: vertex renumbering in first-use order
 //   /root/reference/code/test_dual.py:49-61          overlap merge: sum, count, divide / normalise
-// The ring growth is a strictly ordered traversal (the patch is cut in the middle of a ring at
-// `neighbor_count` faces, in visiting order), so it runs on the host over the CSR incidence; everything
-// that touches per-vertex / per-face data stays on the device.
-#include <vector>
+// The ring growth is an ordered traversal (the patch is cut in the middle of a ring at `neighbor_count` faces, in
+// visiting order); since round 4 it runs on the device as well, ring by ring, with the visiting order recovered from
+// slot numbers (patch_grow_kernel).  Its sequential statement lives with the test infrastructure (oracle/oracle_c.c).
 
 #include "common.h"
 
@@ -76,40 +75,389 @@ __global__ void patch_finalize_kernel(float* __restrict__ Vp, float* __restrict_
   }
 }
 
-}  // namespace
 
-// HOST function over HOST arrays.  vf as CSR (rowptr [V+1], list), the order of `list` inside a vertex
-// is the order the reference walks its padded vf_indices row.
-int patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F, int64_t seed,
-                    int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n) {
-  GEOBI_REQUIRE(F > 0 && seed >= 0 && seed < F, "patch_grow: seed %lld outside [0, %lld)", (long long)seed, (long long)F);
-  if (neighbor_count <= 0) neighbor_count = INT64_MAX;
-  if (ring_count <= 0) ring_count = INT64_MAX;
-  std::vector<uint8_t> sel((size_t)F, 0);
-  int64_t n = 0;
-  out[n++] = (int32_t)seed;
-  sel[seed] = 1;
-  int64_t ok_start = 0, ok_end = 1;
-  for (int64_t ring = 0; ring < ring_count; ++ring) {
-    for (int64_t q = ok_start; q < ok_end; ++q) {
-      const int32_t face = out[q];
-      for (int k = 0; k < 3; ++k) {
-        const int32_t v = fv[3 * (int64_t)face + k];
-        for (int32_t e = vf_rowptr[v]; e < vf_rowptr[v + 1]; ++e) {
-          const int32_t g = vf_list[e];
-          if (!sel[g]) {
-            out[n++] = g;
-            sel[g] = 1;
-            if (n >= neighbor_count) { *out_n = n; return 0; }
-          }
+// ---------------------------------------------------------------------------------------- ring growth on the device
+// data_util.mesh_get_neighbor_np (code/data_util.py:55-84) is an ORDERED traversal: ring r + 1 lists, in the order they are
+// first met, the unselected faces found by walking ring r's faces in order, their three vertices in order, each vertex's
+// incident faces in order; the patch is cut the moment `neighbor_count` faces are listed.
+//
+// Level-synchronous form, one workgroup per patch (a ring is a few hundred to a few thousand faces: a chip-wide launch per
+// ring would cost more in launches than the ring in work).  Number the (ring face q, vertex k) pairs of a ring p = 3 q + k
+// ("items") and an item's incidence entries (p, e).  Two facts carry the order:
+//   * a vertex only matters where it is met FIRST in the patch: every face around it is selected right there, so later
+//     meetings find nothing.  Items whose vertex was expanded in an earlier ring are dropped (a bitmap); among the items of
+//     one ring the smallest p per vertex wins (atomicMin of p on the vertex's entry of an LDS hash table).  That leaves
+//     ~1/6 of the (q, k, e) triples the sequential loop walks.
+//   * a face met by several expanding items is listed where the smallest (p, e) meets it (atomicMin of p W + e on the
+//     face's entry of a second table), and its place in the new ring is the number of winning (p, e) before its own: lanes
+//     own items in ascending order, so that is a wave prefix sum plus the totals of the waves before.
+// The cut is "the first `room` winners".  The current ring's vertex rows sit in LDS; the "selected" / "expanded" flags are
+// LDS bitmaps when the mesh fits them (262 144 faces, 131 072 vertices), per-patch stamps in HBM otherwise.  The kernel
+// ends by picking the next patch's seed -- the unvisited face farthest from the centroid, lowest id on ties like np.argmax
+// (code/dataset.py:159,188-190) -- so a chain of these launches splits a whole mesh with no host step in between.
+// Measured on the way (MI355X, 20 000-face patches of a 151 k-face mesh, ~59 rings): all (q, k, e) triples with atomicMin
+// on a global per-face key 0.8-1.0 ms per patch; the same with the LDS table 0.8 ms (phase times by s_memtime: the 12.6 k
+// incidence loads of a ring 11 k cycles, their hash inserts 11 k, append 5 k, barriers 3 k of 37 k per ring); the host
+// loop it replaces 0.37 ms.
+constexpr int kGrowThreads = 1024;
+constexpr int kGrowRingLds = 2048;        // ring faces whose vertex rows are kept in LDS (2 buffers x 24 KB)
+constexpr int kGrowIter = 4;              // items per lane and pass
+constexpr int kGrowIter2 = 8;             // (vertex, entry) slots per lane and pass
+constexpr int kGrowWinners = 2048;        // expanding vertices a pass lists
+constexpr int kGrowFaceTab = 4096;        // (face id, first slot) entries: 32 KB
+constexpr int kGrowVertTab = 2048;        // (vertex id, first item) entries: 16 KB
+constexpr int kGrowFaceBits = 262144, kGrowVertBits = 131072; // 32 KB + 16 KB of LDS bitmaps
+
+// dynamic LDS layout (ints)
+constexpr int kOffFv = 0;
+constexpr int kOffFaceTab = kOffFv + 2 * 3 * kGrowRingLds;
+constexpr int kOffVertTab = kOffFaceTab + 2 * kGrowFaceTab;
+constexpr int kOffWinners = kOffVertTab + 2 * kGrowVertTab;
+constexpr int kOffFaceBits = kOffWinners + kGrowWinners;
+constexpr int kOffVertBits = kOffFaceBits + kGrowFaceBits / 32;
+constexpr int kGrowLdsInts = kOffVertBits + kGrowVertBits / 32;
+static_assert(kGrowLdsInts * 4 <= 158 * 1024, "the growth kernel's LDS");
+
+// next seed: the unvisited face with the largest d2 (lowest id on ties); state[0] = seed or -1, state[2] = unvisited count.
+// scratch: 3 x kGrowThreads words of LDS.
+__device__ void grow_pick_seed(const float* __restrict__ d2, const int* __restrict__ visited, int F, int* __restrict__ state,
+                               int* scratch) {
+  float* s_d = reinterpret_cast<float*>(scratch);
+  int* s_f = scratch + kGrowThreads;
+  int* s_n = scratch + 2 * kGrowThreads;
+  float bd = 0.f;
+  int bf = -1, left = 0;
+  for (int f0 = threadIdx.x; f0 < F; f0 += 4 * kGrowThreads) {   // four independent (flag, distance) pairs in flight
+    int vis[4];
+    float dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + u * kGrowThreads;
+      vis[u] = f < F ? visited[f] : 1;
+      dd[u] = f < F ? d2[f] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (vis[u]) continue;
+      ++left;
+      if (bf < 0 || dd[u] > bd) { bd = dd[u]; bf = f0 + u * kGrowThreads; }     // ascending f per thread: the first maximum stays
+    }
+  }
+  s_d[threadIdx.x] = bd; s_f[threadIdx.x] = bf; s_n[threadIdx.x] = left;
+  __syncthreads();
+  for (int o = kGrowThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float od = s_d[threadIdx.x + o];
+      const int of = s_f[threadIdx.x + o];
+      const int mf = s_f[threadIdx.x];
+      if (of >= 0 && (mf < 0 || od > s_d[threadIdx.x] || (od == s_d[threadIdx.x] && of < mf))) {
+        s_d[threadIdx.x] = od; s_f[threadIdx.x] = of;
+      }
+      s_n[threadIdx.x] += s_n[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { state[0] = s_f[0]; state[2] = s_n[0]; }
+}
+
+__global__ __launch_bounds__(kGrowThreads) void patch_grow_init_kernel(const float* __restrict__ d2, int F,
+                                                                       int* __restrict__ visited, int* __restrict__ state) {
+  __shared__ int scratch[3 * kGrowThreads];
+  if (threadIdx.x == 0) { state[1] = 0; state[3] = 0; }
+  grow_pick_seed(d2, visited, F, state, scratch);
+}
+
+// Hash tables of a pass (LDS, open addressing, `size` a power of two): entry of `id` (claimed if new) with its value lowered
+// to `rel`.  The FIRST probe of all of a lane's entries is issued back to back by the caller (grow_tab_first: the LDS
+// atomics pipeline; one site after the other, each waiting for its compare-and-swap, was 9 k of a ring's 29 k cycles);
+// grow_tab_rest finishes an entry whose first slot was taken by another id.  More than kGrowProbes probes = the table is
+// too full: the flag makes the caller redo the pass with fewer items.
+constexpr int kGrowProbes = 48;
+
+__device__ __forceinline__ unsigned grow_hash(int id, int shift) { return ((unsigned)id * 2654435761u) >> shift; }
+
+__device__ __forceinline__ int grow_tab_rest(int* t_id, int* t_val, int size, unsigned h, int first_old, int* full, int id,
+                                             int rel) {
+  int old = first_old;
+  for (int probe = 0; probe < kGrowProbes; ++probe) {
+    if (old == -1 || old == id) {
+      atomicMin(&t_val[h], rel);
+      return (int)h;
+    }
+    h = (h + 1) & (size - 1);
+    old = atomicCAS(&t_id[h], -1, id);
+  }
+  full[1] = 1;
+  return -1;
+}
+
+// exclusive prefix of one int per lane over the wave; total = the wave's sum
+__device__ __forceinline__ int grow_wave_scan(int c, int lane, int& total) {
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  total = __shfl(incl, 63, 64);
+  return incl - c;
+}
+
+template <bool LDSBITS>
+__global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
+    const int* __restrict__ fv, const int* __restrict__ vf, int W, int F, int V, const float* __restrict__ d2, int seed_arg,
+    int neighbor_count, int ring_count, int patch_id, int* __restrict__ stamp, int* __restrict__ vstamp,
+    int* __restrict__ visited, int* __restrict__ state, int* __restrict__ sel_out, int* __restrict__ n_out, int* mailbox,
+    int pick_next) {
+  extern __shared__ int s_dyn[];
+  int* s_fv = s_dyn + kOffFv;                         // [2][3 * kGrowRingLds]
+  int* ft_id = s_dyn + kOffFaceTab;                   // face table
+  int* ft_val = ft_id + kGrowFaceTab;
+  int* vt_id = s_dyn + kOffVertTab;                   // vertex table
+  int* vt_val = vt_id + kGrowVertTab;
+  int* wl = s_dyn + kOffWinners;                      // this pass' expanding vertices, in item order
+  unsigned* fbits = reinterpret_cast<unsigned*>(s_dyn + kOffFaceBits);
+  unsigned* vbits = reinterpret_cast<unsigned*>(s_dyn + kOffVertBits);
+  __shared__ int s_wave[32];
+  __shared__ int s_full[2];                           // [1]: a table (or the winner list) overflowed: redo the pass smaller
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int seed = seed_arg >= 0 ? seed_arg : state[0];
+  if (seed < 0 || seed >= F) {                        // every face has been visited: no patch
+    if (t == 0) {
+      if (n_out) n_out[0] = 0;
+      if (mailbox) { __threadfence_system(); *(volatile int*)mailbox = 1; }
+    }
+    return;
+  }
+  if (LDSBITS) {
+    for (int i = t; i < kGrowFaceBits / 32 + kGrowVertBits / 32; i += kGrowThreads) fbits[i] = 0u;   // the two bitmaps are adjacent
+    __syncthreads();
+  }
+  auto face_selected = [&](int g) -> bool { return LDSBITS ? ((fbits[g >> 5] >> (g & 31)) & 1u) != 0u : stamp[g] == patch_id; };
+  auto vertex_expanded = [&](int v) -> bool { return LDSBITS ? ((vbits[v >> 5] >> (v & 31)) & 1u) != 0u : vstamp[v] == patch_id; };
+  auto wave_offsets = [&](int mine, int& woff, int& total) {     // s_wave must hold every wave's count (barrier before)
+    woff = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < kGrowThreads / 64; ++w) {
+      const int c = s_wave[w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    (void)mine;
+  };
+  int n = 1, ring_start = 0, ring_end = 1, cur = 0;
+  if (t == 0) {
+    sel_out[0] = seed; visited[seed] = 1;
+    if (LDSBITS) atomicOr(&fbits[seed >> 5], 1u << (seed & 31)); else stamp[seed] = patch_id;
+  }
+  if (t < 3) s_fv[t] = fv[3 * (size_t)seed + t];
+  __syncthreads();
+  bool ring_lds = true;
+  for (int ring = 0; ring < ring_count && n < neighbor_count; ++ring) {
+    const int R = ring_end - ring_start;
+    const long long items = 3ll * R;
+    const int* ring_fv = s_fv + cur * 3 * kGrowRingLds;
+    int* next_fv = s_fv + (cur ^ 1) * 3 * kGrowRingLds;
+    int added = 0;                                                // faces this ring has appended so far (uniform)
+    // items of one pass: the whole ring when it fits (spread over the waves), halved whenever a pass overflows a table
+    long long pass_items = items < (long long)kGrowThreads * kGrowIter ? items : (long long)kGrowThreads * kGrowIter;
+    long long pass0 = 0;
+    while (pass0 < items && n < neighbor_count) {
+      const long long pass_end = pass0 + pass_items < items ? pass0 + pass_items : items;
+      const int it1 = (int)((pass_end - pass0 + kGrowThreads - 1) / kGrowThreads);
+      for (int i = t; i < kGrowFaceTab; i += kGrowThreads) { ft_id[i] = -1; ft_val[i] = 0x7fffffff; }
+      for (int i = t; i < kGrowVertTab; i += kGrowThreads) { vt_id[i] = -1; vt_val[i] = 0x7fffffff; }
+      if (t == 0) { s_full[0] = 0; s_full[1] = 0; }
+      __syncthreads();
+      // ---- 1: the item's vertex; unexpanded vertices enter the vertex table with their item number
+      const long long base = pass0 + (long long)wave * (64 * it1) + lane;
+      int vtx[kGrowIter], vh[kGrowIter];
+#pragma unroll
+      for (int i = 0; i < kGrowIter; ++i) {
+        const long long p = base + 64 * i;
+        vtx[i] = -1; vh[i] = -2;
+        if (i < it1 && p < pass_end) {
+          const int q = (int)(p / 3), k = (int)(p - 3ll * q);
+          const int v = ring_lds ? ring_fv[3 * q + k] : fv[3 * (size_t)sel_out[ring_start + q] + k];
+          if (!vertex_expanded(v)) { vtx[i] = v; vh[i] = atomicCAS(&vt_id[grow_hash(v, 21)], -1, v); }
         }
       }
+#pragma unroll
+      for (int i = 0; i < kGrowIter; ++i)
+        vh[i] = vtx[i] >= 0 ? grow_tab_rest(vt_id, vt_val, kGrowVertTab, grow_hash(vtx[i], 21), vh[i], s_full, vtx[i],
+                                             (int)(base + 64 * i - pass0))
+                            : -1;
+      __syncthreads();
+      // ---- 1b: items that met their vertex first, compacted in item order -> wl
+      unsigned long long fm[kGrowIter];
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < kGrowIter; ++i) {
+        const bool first = vh[i] >= 0 && vt_val[vh[i]] == (int)(base + 64 * i - pass0);
+        fm[i] = __ballot(first);
+        cnt += __popcll(fm[i]);
+      }
+      if (lane == 0) s_wave[wave] = cnt;
+      __syncthreads();
+      int woff, nw;
+      wave_offsets(cnt, woff, nw);
+      const long long slots = (long long)nw * W;
+      if (s_full[1] || nw > kGrowWinners || slots > (long long)kGrowThreads * kGrowIter2) {   // too much for one pass
+        __syncthreads();
+        pass_items = pass_items > 1 ? pass_items / 2 : 1;        // one item expands at most W <= 8192 slots: always fits
+        continue;
+      }
+      {
+        int running = woff;
+#pragma unroll
+        for (int i = 0; i < kGrowIter; ++i) {
+          if ((fm[i] >> lane) & 1ull) {
+            wl[running + __popcll(fm[i] & lt_mask)] = vtx[i];
+            if (LDSBITS) atomicOr(&vbits[vtx[i] >> 5], 1u << (vtx[i] & 31)); else vstamp[vtx[i]] = patch_id;
+          }
+          running += __popcll(fm[i]);
+        }
+      }
+      __syncthreads();
+      // ---- 2: slots (expanding vertex j, incidence entry e): unselected faces enter the face table with their slot number
+      int it2 = (int)((slots + kGrowThreads - 1) / kGrowThreads);
+      it2 = it2 < 1 ? 1 : it2;                                    // <= kGrowIter2 (checked above)
+      const int base2 = wave * (64 * it2) + lane;
+      int gg[kGrowIter2], fh[kGrowIter2];
+#pragma unroll
+      for (int i = 0; i < kGrowIter2; ++i) {
+        const int sl = base2 + 64 * i;
+        gg[i] = -1;
+        if (i < it2 && sl < slots) {
+          const int j = sl / W, e = sl - j * W;
+          gg[i] = vf[(size_t)wl[j] * W + e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kGrowIter2; ++i) {
+        fh[i] = -2;
+        if (gg[i] >= 0 && !face_selected(gg[i])) fh[i] = atomicCAS(&ft_id[grow_hash(gg[i], 20)], -1, gg[i]);
+        else gg[i] = -1;
+      }
+#pragma unroll
+      for (int i = 0; i < kGrowIter2; ++i)
+        fh[i] = gg[i] >= 0 ? grow_tab_rest(ft_id, ft_val, kGrowFaceTab, grow_hash(gg[i], 20), fh[i], s_full, gg[i], base2 + 64 * i)
+                           : -1;
+      __syncthreads();
+      if (s_full[1]) {                                            // more new faces than the table holds: smaller pass
+        // the vertices this pass marked expanded have not listed their faces yet: take the marks back
+        for (int j = t; j < nw; j += kGrowThreads) {
+          const int v = wl[j];
+          if (LDSBITS) atomicAnd(&vbits[v >> 5], ~(1u << (v & 31))); else vstamp[v] = 0;
+        }
+        __syncthreads();
+        pass_items = pass_items > 1 ? pass_items / 2 : 1;
+        continue;
+      }
+      // ---- 3: winners in slot order -> positions
+      unsigned long long wm[kGrowIter2];
+      cnt = 0;
+#pragma unroll
+      for (int i = 0; i < kGrowIter2; ++i) {
+        wm[i] = __ballot(fh[i] >= 0 && ft_val[fh[i]] == base2 + 64 * i);
+        cnt += __popcll(wm[i]);
+      }
+      if (lane == 0) s_wave[wave] = cnt;
+      __syncthreads();
+      int total;
+      wave_offsets(cnt, woff, total);
+      // ---- 4: append
+      const int room = neighbor_count - n;
+      const int take = total < room ? total : room;
+      {
+        int running = woff;
+#pragma unroll
+        for (int i = 0; i < kGrowIter2; ++i) {
+          if ((wm[i] >> lane) & 1ull) {
+            const int idx = running + __popcll(wm[i] & lt_mask);
+            if (idx < room) {
+              const int g = gg[i];
+              sel_out[n + idx] = g;
+              visited[g] = 1;
+              if (LDSBITS) atomicOr(&fbits[g >> 5], 1u << (g & 31)); else stamp[g] = patch_id;
+            }
+          }
+          running += __popcll(wm[i]);
+        }
+      }
+      __syncthreads();
+      n += take;
+      added += take;
+      pass0 = pass_end;
     }
-    ok_start = ok_end;
-    ok_end = n;
-    if (ok_start == ok_end) break;
+    ring_lds = added <= kGrowRingLds;
+    ring_start = ring_end;
+    ring_end = n;
+    cur ^= 1;
+    if (ring_start == ring_end) break;
+    if (ring_lds) {
+      // the new ring's vertex rows into LDS, one face per thread and step: the ids were just listed (cache-hot), the rows are
+      // ONE round trip for the whole ring
+      for (int j = t; j < added; j += kGrowThreads) {
+        const int g = sel_out[ring_start + j];
+        int* row = next_fv + 3 * j;
+        row[0] = fv[3 * (size_t)g]; row[1] = fv[3 * (size_t)g + 1]; row[2] = fv[3 * (size_t)g + 2];
+      }
+      __syncthreads();
+    }
   }
-  *out_n = n;
+  __syncthreads();
+  if (pick_next) grow_pick_seed(d2, visited, F, state, s_dyn);    // the tables are dead: their LDS is the scratch
+  __syncthreads();
+  if (t == 0) {
+    state[1] += 1;
+    if (n_out) n_out[0] = n;
+    if (mailbox) { __threadfence_system(); *(volatile int*)mailbox = 1 + 2 * n; }
+  }
+}
+
+}  // namespace
+
+size_t patch_grow_state_ints(int64_t F, int64_t V) { return (size_t)2 * (size_t)F + (size_t)V + 8; }
+
+// state (int32): [stamp F | visited F | vertex stamp V | seed, patches, unvisited, error, ...]
+int patch_grow_init(int32_t* state, int64_t F, int64_t V, const float* d2, hipStream_t s) {
+  GEOBI_REQUIRE(F > 0 && V > 0, "patch_grow_init: empty mesh");
+  GEOBI_HIP(hipMemsetAsync(state, 0, sizeof(int) * ((size_t)2 * F + V + 8), s));      // no patch has id 0
+  patch_grow_init_kernel<<<1, kGrowThreads, 0, s>>>(d2, (int)F, state + F, state + 2 * F + V);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F, int64_t V, const float* d2, int64_t seed,
+               int64_t neighbor_count, int64_t ring_count, int patch_id, int32_t* state, int32_t* sel_out, int32_t* n_out,
+               int32_t* mailbox, int pick_next, hipStream_t s) {
+  GEOBI_REQUIRE(F > 0 && V > 0 && maxval > 0, "patch_grow: empty mesh");
+  GEOBI_REQUIRE(patch_id > 0, "patch_grow: patch ids start at 1 (0 marks a face no patch of this split holds)");
+  GEOBI_REQUIRE(seed < F, "patch_grow: seed %lld outside [0, %lld)", (long long)seed, (long long)F);
+  GEOBI_REQUIRE(maxval <= kGrowIter2 * kGrowThreads, "patch_grow: a vertex with %d incident faces", maxval);
+  GEOBI_REQUIRE(pick_next == 0 || d2 != nullptr, "patch_grow: picking the next seed needs d2");
+  const int nc = (neighbor_count <= 0 || neighbor_count > F) ? (int)F : (int)neighbor_count;
+  const int rc = (ring_count <= 0 || ring_count > F) ? (int)F : (int)ring_count;
+  constexpr size_t lds = (size_t)kGrowLdsInts * sizeof(int);
+  int32_t* scalars = state + 2 * F + V;
+  const bool bits = F <= kGrowFaceBits && V <= kGrowVertBits;
+#define GEOBI_GROW(B)                                                                                                  \
+  do {                                                                                                                 \
+    static std::atomic<bool> attr_set{false};                                                                          \
+    if (!attr_set) {                                                                                                   \
+      GEOBI_HIP(hipFuncSetAttribute((const void*)patch_grow_kernel<B>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                    (int)lds));                                                                        \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    patch_grow_kernel<B><<<1, kGrowThreads, lds, s>>>(fv, vf, maxval, (int)F, (int)V, d2, (int)seed, nc, rc, patch_id,  \
+                                                      state, state + 2 * F, state + F, scalars, sel_out, n_out,        \
+                                                      mailbox, pick_next);                                             \
+  } while (0)
+  if (bits) GEOBI_GROW(true); else GEOBI_GROW(false);
+#undef GEOBI_GROW
+  GEOBI_LAUNCH_OK();
   return 0;
 }
 

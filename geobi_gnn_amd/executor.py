@@ -358,6 +358,12 @@ def forward_train(net, data_v, data_f):
     return verts, normals, Recorded(handle.value, arena, keep, net, corner)
 
 
+# Data-parallel overlap (parallel.GradBucket.all_reduce_mean_split): two torch.cuda.Event objects that the NEXT backward
+# records where the facet half of the gradients is final (geobi_net_backward_facet_events).  Set here, not through the
+# library from the caller's thread: autograd runs this backward on its own device thread, and the hook is per host thread.
+FACET_EVENTS = None
+
+
 def backward(rec, g_verts, g_normals, params):
     """Parameter gradients of a recorded forward, aligned with `params` (None where the kernels added straight into a
     direct-gradient bucket view, see ops._direct_grad)."""
@@ -371,6 +377,9 @@ def backward(rec, g_verts, g_normals, params):
     cidx = rec.corner.get()
     gv = None if g_verts is None else _f32(g_verts, 'grad of verts')
     gn = None if g_normals is None else _f32(g_normals, 'grad of normals')
+    if FACET_EVENTS is not None:
+        L.lib().geobi_net_backward_facet_events(ctypes.c_void_p(FACET_EVENTS[0].cuda_event),
+                                                ctypes.c_void_p(FACET_EVENTS[1].cuda_event))
     rc = L.lib().geobi_net_backward(ctypes.c_int64(rec.handle), None if gv is None else gv.data_ptr(),
                                     None if gn is None else gn.data_ptr(), ctypes.byref(gp), 1 if use_direct else 0,
                                     cidx.segptr.data_ptr(), cidx.members.data_ptr(), L.stream())

@@ -40,15 +40,20 @@ def vertex_faces(faces, num_vertices):
     return rowptr, lst[:3 * F]
 
 
-def vf_padded(rowptr, lst, num_vertices):
-    """openmesh ``vf_indices``: [V, max_valence] int64, -1 padded (what update_position2 takes)."""
+def vf_padded32(rowptr, lst, num_vertices):
+    """openmesh ``vf_indices`` as int32: [V, max_valence], -1 padded (what the device ring growth walks)."""
     dev = rowptr.device
     m = torch.zeros(1, dtype=torch.int32, device=dev)
     L.call('geobi_max_degree', L.ptr(rowptr), int(num_vertices), L.ptr(m), L.stream())
     maxval = max(L.read_i32(m, 1)[0], 1)
     vf = torch.empty((int(num_vertices), maxval), dtype=torch.int32, device=dev)
     L.call('geobi_vf_padded', L.ptr(rowptr), L.ptr(lst), int(num_vertices), maxval, L.ptr(vf), L.stream())
-    return vf.long()
+    return vf
+
+
+def vf_padded(rowptr, lst, num_vertices):
+    """openmesh ``vf_indices``: [V, max_valence] int64, -1 padded (what update_position2 takes)."""
+    return vf_padded32(rowptr, lst, num_vertices).long()
 
 
 def mesh_normals(points, faces, rowptr, lst):
@@ -122,11 +127,13 @@ def _reference_coo(graph, weight, normal, loops_inline):
 
 
 def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type='Synthetic', device=None,
-                    reference_layout=False, centroid=None, scale=None):
+                    reference_layout=False, centroid=None, scale=None, trusted_faces=False, want_vf=True):
     """(points [V,3], faces [F,3]) -> (data_v, data_f) as process_one_submesh + post_processing emit them,
     computed on the device.  Same fields as ``meshgen.build_dual_data`` (incl. ``data_v.meta``).
     ``centroid`` [1,3] / ``scale``: normalisation of the WHOLE mesh when this is one patch of it
-    (dataset.py:177-178 overwrite the patch's own values)."""
+    (dataset.py:177-178 overwrite the patch's own values).
+    trusted_faces: the face table was produced by this library (a patch of geobi_submesh): no range check.
+    want_vf=False: no padded vf table in ``data_v.meta`` (a patch is never vertex-updated on its own)."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     if not torch.cuda.is_available():
         raise L.GeobiError('meshprep.build_dual_data runs on the MI355X only (no CPU fallback); '
@@ -135,13 +142,40 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
     pts = pts.to(device=dev, dtype=torch.float32).contiguous()
     fv = _dev_i32(faces, dev)
     V, F = pts.shape[0], fv.shape[0]
-    if F > 0 and (int(fv.min()) < 0 or int(fv.max()) >= V):
-        raise L.GeobiError('faces index vertices outside [0, %d)' % V)
 
+    # A face table from outside is range-checked BEFORE any kernel walks it (a bad vertex id is a faulting gather); one
+    # produced by this library (a patch of geobi_submesh) is not.
+    if not trusted_faces and F > 0:
+        lo, hi = L.read_i32(torch.cat([t.reshape(1) for t in torch.aminmax(fv)]))
+        if lo < 0 or hi >= V:
+            raise L.GeobiError('faces index vertices outside [0, %d)' % V)
+    # Everything else whose size the host must know before it can allocate comes back in ONE read: both graphs' edge
+    # counts and the largest valence (width of the padded vf table).  Until round 4 these were separate reads.
     rowptr_vf, lst = vertex_faces(fv, V)
+    rp_v = torch.empty(V + 1, dtype=torch.int32, device=dev)
+    rp_f = torch.empty(F + 1, dtype=torch.int32, device=dev)
+    for kind, n, rp in ((0, V, rp_v), (1, F, rp_f)):
+        ws = L.workspace(L.size_query('geobi_ring_graph_ws_bytes', n), dev)
+        L.call('geobi_ring_graph_count', kind, L.ptr(fv), L.ptr(rowptr_vf), L.ptr(lst), n, L.ptr(rp), L.ptr(ws), ws.numel(),
+               L.stream())
+    parts = [rp_v[V:V + 1], rp_f[F:F + 1]]
+    if want_vf:
+        m = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call('geobi_max_degree', L.ptr(rowptr_vf), V, L.ptr(m), L.stream())
+        parts.append(m)
+    sizes = L.read_i32(torch.cat(parts))
+    E_v, E_f = sizes[0], sizes[1]
+
+    def finish_graph(kind, n, rp, E):
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
+        L.call('geobi_ring_graph_fill', kind, L.ptr(fv), L.ptr(rowptr_vf), L.ptr(lst), n, L.ptr(rp), L.ptr(col), L.stream())
+        g = Graph(n, dev)
+        g.rowptr_out, g.col_out, g.E = rp, col, E
+        g.symmetric = True                                  # sharing a face / a vertex is a symmetric relation
+        return g
     fn, pos_f, vn = mesh_normals(pts, fv, rowptr_vf, lst)
-    g_v = ring_graph(0, fv, rowptr_vf, lst, V)
-    g_f = ring_graph(1, fv, rowptr_vf, lst, F)
+    g_v = finish_graph(0, V, rp_v, E_v)
+    g_f = finish_graph(1, F, rp_f, E_f)
 
     # center_and_scale, s_type 0: centroid = mean vertex, scale = 1 / mean mesh-edge length
     if centroid is None:
@@ -176,5 +210,11 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
         gt_c = torch.empty((F, 3), dtype=torch.float32, device=dev)
         L.call('geobi_mesh_normals', L.ptr(pg), L.ptr(fv), F, V, None, None, L.ptr(gt_fn), L.ptr(gt_c), None, L.stream())
         data_f.y = gt_fn
-    data_v.meta = {'centroid': cen, 'scale': sc, 'vf_indices': vf_padded(rowptr_vf, lst, V)}
+    vf = None
+    if want_vf:
+        maxval = max(sizes[2], 1)
+        vf = torch.empty((V, maxval), dtype=torch.int32, device=dev)
+        L.call('geobi_vf_padded', L.ptr(rowptr_vf), L.ptr(lst), V, maxval, L.ptr(vf), L.stream())
+        vf = vf.long()
+    data_v.meta = {'centroid': cen, 'scale': sc, 'vf_indices': vf, 'incidence': (rowptr_vf, lst)}
     return data_v, data_f

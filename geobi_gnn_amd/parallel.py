@@ -117,6 +117,40 @@ class GradBucket(object):
         if self.owner is not None and self.owner.grad is not self.flat:
             self.owner.grad = self.flat
 
+    def facet_offset(self, net):
+        """Element offset in `flat` where the facet half (gnn_f, fc_f1, fc_f2) starts: DualGNN registers gnn_v, fc_v1,
+        fc_v2 first, so the halves are two contiguous ranges.  Its gradients are final BEFORE the vertex branch's
+        backward runs (the backward walks facet head -> gnn_f -> coupling -> vertex head -> gnn_v)."""
+        first = next(net.gnn_f.parameters())
+        off = 0
+        for p in self.params:
+            if p is first:
+                return off
+            off += p.numel()
+        raise ValueError('the bucket does not hold the network\'s parameters')
+
+    def all_reduce_mean_split(self, offset, events=None, comm_stream=None):
+        """The same reduction as `all_reduce_mean` in two collectives: the tail [offset:] (the facet half) FIRST -- on
+        `comm_stream` behind `events` (torch.cuda.Event list recorded by geobi_net_backward_facet_events) when given, so
+        that it runs under the vertex branch's backward -- then the head [:offset].  Element-wise the same sums, so the
+        reduced bucket is identical to the one-shot all-reduce."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return self.flat
+        world = dist.get_world_size()
+        tail, head = self.flat[offset:], self.flat[:offset]
+        if events and self.flat.is_cuda and comm_stream is not None:
+            for ev in events:
+                comm_stream.wait_event(ev)
+            with torch.cuda.stream(comm_stream):
+                work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+            dist.all_reduce(head, op=dist.ReduceOp.SUM)          # behind the whole backward, on the compute stream
+            work.wait()                                          # the compute stream waits for the early collective
+        else:
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+            dist.all_reduce(head, op=dist.ReduceOp.SUM)
+        self.flat.div_(world)
+        return self.flat
+
     def all_reduce_mean(self):
         """Sum over ranks then divide by the world size (= the reference's loss / batch_size)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -6,10 +6,11 @@
 * merge  /root/reference/code/test_dual.py:49-61 (sum overlapping predictions, divide by the visit count,
          re-normalise the normals) followed by the 60-sweep vertex update (:63-72)
 
-The ordered ring growth runs on the host (C++, ``geobi_patch_grow_host``); vertex renumbering, graph
-construction, the network and the merge run on the device.  The reference walks openmesh's ``vf_indices``
-rows; here the incidence lists are in ascending face order, so which faces the LAST, partial ring of a
-patch contributes can differ from an openmesh run (whole rings do not depend on the order).
+Everything runs on the device: the ordered ring growth (``geobi_patch_grow``: one workgroup per patch walks the rings,
+the visiting order comes from slot numbers; the chain of patches runs on a side stream), vertex renumbering, graph
+construction, the network and the merge.  The reference walks openmesh's ``vf_indices`` rows; here the incidence
+lists are in ascending face order, so which faces the LAST, partial ring of a patch contributes can differ from an
+openmesh run (whole rings do not depend on the order).
 """
 import ctypes
 
@@ -22,14 +23,30 @@ from .data_util import computer_face_normal, update_position2
 from .infer import predict_one_submesh
 
 
-def patch_grow(fv_host, rowptr_host, list_host, seed, neighbor_count=None, ring_count=None):
-    """data_util.mesh_get_neighbor_np on host arrays (int32, C-contiguous) -> face ids in visiting order."""
-    F = fv_host.shape[0]
-    out = np.empty(F, dtype=np.int32)
-    n = ctypes.c_int64(0)
-    L.call('geobi_patch_grow_host', fv_host.ctypes.data, rowptr_host.ctypes.data, list_host.ctypes.data, F, int(seed),
-           int(neighbor_count or 0), int(ring_count or 0), out.ctypes.data, ctypes.byref(n))
-    return out[:n.value]
+_GROW_STREAMS = {}
+
+
+def _grow_stream(dev):
+    """One side stream per device for the growth chain: it runs beside the patches' own work on the caller's stream."""
+    key = (dev.type, dev.index)
+    if key not in _GROW_STREAMS:
+        _GROW_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _GROW_STREAMS[key]
+
+
+def patch_grow(fv, vf32, seed, neighbor_count=None, ring_count=None):
+    """data_util.mesh_get_neighbor_np on the device (geobi_patch_grow), one patch from a given seed: fv [F,3] int32,
+    vf32 [V,maxval] int32 padded incidence -> face ids (device int32) in the reference's visiting order."""
+    dev = fv.device
+    F, V = int(fv.shape[0]), int(vf32.shape[0])
+    state = torch.empty(L.size_query('geobi_patch_grow_state_ints', F, V), dtype=torch.int32, device=dev)
+    d2 = torch.zeros(F, dtype=torch.float32, device=dev)
+    L.call('geobi_patch_grow_init', L.ptr(state), F, V, L.ptr(d2), L.stream())
+    out = torch.empty(F, dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.call('geobi_patch_grow', L.ptr(fv), L.ptr(vf32), int(vf32.shape[1]), F, V, None, int(seed), int(neighbor_count or 0),
+           int(ring_count or 0), 1, L.ptr(state), L.ptr(out), L.ptr(n), None, 0, L.stream())
+    return out[:L.read_i32(n, 1)[0]]
 
 
 def submesh(fv, sel, num_vertices):
@@ -45,36 +62,72 @@ def submesh(fv, sel, num_vertices):
     return v_idx[:L.read_i32(count, 1)[0]], f_sub
 
 
-def split_patches(points, fv, submesh_size, incidence=None, keep=None):
-    """Generator over the patches of dataset.py:156-193: yields (select_faces, V_idx, F_sub) device int32
-    tensors.  points [V,3] fp32 and fv [F,3] int32 live on the device.
-    keep: optional callable(k) -> bool.  Patch k is still grown (the next seed depends on every earlier patch) but
-    when keep(k) is false nothing is built on the device and None is yielded -- how the ranks of a multi-GPU
-    inference each take their share of one mesh's patches."""
-    V, F = points.shape[0], fv.shape[0]
-    rowptr, lst = incidence if incidence is not None else meshprep.vertex_faces(fv, V)
-    fv_h = fv.cpu().numpy()
-    rp_h, ls_h = rowptr.cpu().numpy(), lst.cpu().numpy()
+def split_faces(points, fv, submesh_size, incidence=None, vf32=None, ahead=None):
+    """The face lists of dataset.py:156-193's patches, grown on the device: generator of (seed-ordered) device int32
+    tensors.  The whole split is a CHAIN of geobi_patch_grow launches on a side stream -- each grows one patch and picks the
+    next seed (farthest unvisited face) -- enqueued `ahead` patches at a time; a patch's size reaches the host through
+    mapped memory when its kernel ends, so the host only ever waits for the patch it is about to use, and the chain runs
+    beside whatever the caller does with the earlier patches on its own stream."""
+    dev = fv.device
+    V, F = int(points.shape[0]), int(fv.shape[0])
+    sub = int(min(submesh_size, F))
+    if vf32 is None:
+        rowptr, lst = incidence if incidence is not None else meshprep.vertex_faces(fv, V)
+        vf32 = meshprep.vf_padded32(rowptr, lst, V)
+    W = int(vf32.shape[1])
     centroid = points.mean(0, keepdim=True)
-    face_cent = points[fv.long()].mean(1)
-    d2 = ((face_cent - centroid) ** 2).sum(1).cpu().numpy()
-    flag = np.zeros(F, dtype=bool)
-    seed = int(np.argmax(d2))
+    d2 = ((points[fv.long()].mean(1) - centroid) ** 2).sum(1).contiguous()
+    state = torch.empty(L.size_query('geobi_patch_grow_state_ints', F, V), dtype=torch.int32, device=dev)
+    L.call('geobi_patch_grow_init', L.ptr(state), F, V, L.ptr(d2), L.stream())
+    main, gs = torch.cuda.current_stream(dev), _grow_stream(dev)
+    gs.wait_stream(main)
+    ahead = int(ahead or min(32, 2 * (F + sub - 1) // sub + 2))
     k = 0
     while True:
-        sel_h = patch_grow(fv_h, rp_h, ls_h, seed, neighbor_count=submesh_size)
-        flag[sel_h] = True
+        box_ptr = ctypes.c_void_p(0)
+        L.call('geobi_host_mailbox', ahead, ctypes.byref(box_ptr))
+        box = (ctypes.c_int32 * ahead).from_address(box_ptr.value)
+        with torch.cuda.stream(gs):
+            slab = torch.empty(ahead * sub, dtype=torch.int32, device=dev)
+            events = []
+            for i in range(ahead):
+                L.call('geobi_patch_grow', L.ptr(fv), L.ptr(vf32), W, F, V, L.ptr(d2), -1, sub, 0, k + i + 1, L.ptr(state),
+                       slab.data_ptr() + 4 * i * sub, None, box_ptr.value + 4 * i, 1, gs.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(gs)
+                events.append(ev)
+        slab.record_stream(main)
+        for i in range(ahead):
+            spins = 0
+            while box[i] == 0:
+                spins += 1
+                if (spins & 0xfff) == 0 and gs.query() and box[i] == 0:
+                    raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % (k + i))
+            n = (box[i] - 1) // 2
+            if n == 0:
+                for j in range(i + 1, ahead):          # the rest of the round only reports "no patch": let it, the
+                    while box[j] == 0:                 # mailbox is handed out again by the next split
+                        pass
+                return
+            main.wait_event(events[i])
+            yield slab[i * sub:i * sub + n]
+        k += ahead
+
+
+def split_patches(points, fv, submesh_size, incidence=None, keep=None, vf32=None):
+    """Generator over the patches of dataset.py:156-193: yields (select_faces, V_idx, F_sub) device int32
+    tensors.  points [V,3] fp32 and fv [F,3] int32 live on the device; the face lists come from the device growth chain
+    (split_faces), vertex renumbering (get_submesh, data_util.py:318-336) from geobi_submesh.
+    keep: optional callable(k) -> bool.  Patch k is still grown (the next seed depends on every earlier patch) but
+    when keep(k) is false nothing is built for it and None is yielded -- how the ranks of a multi-GPU inference each
+    take their share of one mesh's patches."""
+    V = points.shape[0]
+    for k, sel in enumerate(split_faces(points, fv, submesh_size, incidence=incidence, vf32=vf32)):
         if keep is None or keep(k):
-            sel = torch.from_numpy(sel_h).to(fv.device)
             v_idx, f_sub = submesh(fv, sel, V)
             yield sel, v_idx, f_sub
         else:
             yield None
-        k += 1
-        left = np.where(~flag)[0]
-        if left.size == 0:
-            break
-        seed = int(left[np.argmax(d2[left])])
 
 
 def _union_dual(duals):
@@ -86,8 +139,28 @@ def _union_dual(duals):
     return (data_v, data_f), list(zip(pv[:-1], pv[1:])), list(zip(pf[:-1], pf[1:]))
 
 
+class _Phases(object):
+    """Optional phase clock of predict_mesh (``stats`` dict): wall time per phase with a device sync behind each, so
+    the shares are upper bounds of what the phases cost when they overlap.  Without ``stats`` nothing is synchronised."""
+
+    def __init__(self, stats):
+        self.stats = stats
+        if stats is not None:
+            import time
+            self.clock = time.perf_counter
+            torch.cuda.synchronize()
+            self.t = self.clock()
+
+    def tick(self, name):
+        if self.stats is not None:
+            torch.cuda.synchronize()
+            now = self.clock()
+            self.stats[name] = self.stats.get(name, 0.0) + (now - self.t)
+            self.t = now
+
+
 def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=8,
-                 distributed=None):
+                 distributed=None, stats=None):
     """test_dual.py:24-87 without the OBJ IO, for a mesh of any size: preprocessing, patch split when
     F > sub_size, network, merge, de-normalisation, vertex update -- all device-resident.  The reference runs
     the patches one by one; here `patch_batch` of them go through the network as one disjoint-union graph
@@ -99,6 +172,10 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     (parallel.reduce_patch_sums) adds them, and rank 0 finalises and runs the vertex update.  No graph is split
     across GPUs and nothing but those three sums crosses xGMI.  Other ranks get Vp = Np = V_updated = None.
 
+    stats: optional dict; seconds per phase are ADDED to its keys 'preprocessing' (incidence, graphs, weights,
+    features -- of the mesh or of its patches), 'growth' (patch split: ring growth, seeds, vertex renumbering),
+    'network', 'merge+update' (overlap merge, de-normalisation, vertex update, errors).
+
     Returns dict(Vp, Np, V_updated, n_patches, angle1, angle2)."""
     from . import parallel
     rank, world = parallel.rank_world() if distributed is None or distributed else (0, 1)
@@ -108,19 +185,34 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     fv = torch.as_tensor(np.asarray(faces) if not torch.is_tensor(faces) else faces).to(device=dev, dtype=torch.int32)
     fv = fv.contiguous()
     V, F = pts.shape[0], fv.shape[0]
-    rowptr, lst = meshprep.vertex_faces(fv, V)
-    g_v = meshprep.ring_graph(0, fv, rowptr, lst, V)
-    centroid = pts.mean(0, keepdim=True)
-    scale = float((1.0 / meshprep.mean_edge_length(pts, g_v)).item())
-
+    ph = _Phases(stats)
+    if F > 0:                          # the caller's face table: range-checked before any kernel walks it
+        lo, hi = L.read_i32(torch.cat([t.reshape(1) for t in torch.aminmax(fv)]))
+        if lo < 0 or hi >= V:
+            raise L.GeobiError('faces index vertices outside [0, %d)' % V)
+    vf = None
     if F <= sub_size:
         n_patches = 1
         if rank != 0:                  # one patch: nothing to share out
             return {'Vp': None, 'Np': None, 'V_updated': None, 'n_patches': 1, 'angle1': None, 'angle2': None}
-        dual = meshprep.build_dual_data(pts, fv, name='mesh', data_type=data_type, device=dev)
+        # the mesh's own preprocessing yields incidence, centroid, scale and the padded vf table on its way
+        dual = meshprep.build_dual_data(pts, fv, name='mesh', data_type=data_type, device=dev, trusted_faces=True)
+        meta = dual[0].meta
+        centroid, scale, vf = meta['centroid'], meta['scale'], meta['vf_indices']
+        rowptr, lst = meta['incidence']
+        ph.tick('preprocessing')
         Vp, Np = predict_one_submesh(net, dual)
+        ph.tick('network')
         Vp = Vp / scale + centroid
     else:
+        rowptr, lst = meshprep.vertex_faces(fv, V)
+        vf32 = meshprep.vf_padded32(rowptr, lst, V)
+        vf = vf32.long()
+        g_v = meshprep.ring_graph(0, fv, rowptr, lst, V)
+        centroid = pts.mean(0, keepdim=True)
+        host = torch.cat([meshprep.mean_edge_length(pts, g_v), centroid.reshape(-1)]).tolist()     # one read for both
+        scale, c = float(1.0 / torch.tensor(host[0], dtype=torch.float32)), host[1:]
+        ph.tick('preprocessing')
         Vp = torch.zeros((V, 3), dtype=torch.float32, device=dev)
         Np = torch.zeros((F, 3), dtype=torch.float32, device=dev)
         sum_v = torch.zeros(V, dtype=torch.int32, device=dev)
@@ -134,20 +226,26 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
                 dual, vr, fr = pending[0][2], [(0, pending[0][1].shape[0])], [(0, pending[0][0].shape[0])]
             else:
                 dual, vr, fr = _union_dual([p[2] for p in pending])
+            ph.tick('preprocessing')
             vert_p, norm_p = predict_one_submesh(net, dual)
+            ph.tick('network')
             for (sel, v_idx, _), (v0, v1), (f0, f1) in zip(pending, vr, fr):
                 L.call('geobi_patch_accumulate', L.ptr(vert_p[v0:v1]), L.ptr(norm_p[f0:f1]), L.ptr(v_idx), L.ptr(sel),
                        v_idx.shape[0], sel.shape[0], L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), L.stream())
             del pending[:]
+            ph.tick('merge+update')
 
         keep = None if world == 1 else (lambda k: parallel.owns_patch(k, rank, world))
-        for part in split_patches(pts, fv, sub_size, incidence=(rowptr, lst), keep=keep):
+        for part in split_patches(pts, fv, sub_size, incidence=(rowptr, lst), keep=keep, vf32=vf32):
             n_patches += 1
             if part is None:
                 continue
             sel, v_idx, f_sub = part
+            ph.tick('growth')
             dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, name='patch%d' % (n_patches - 1),
-                                            data_type=data_type, device=dev, centroid=centroid, scale=scale)
+                                            data_type=data_type, device=dev, centroid=centroid, scale=scale,
+                                            trusted_faces=True, want_vf=False)
+            ph.tick('preprocessing')
             pending.append((sel, v_idx, dual))
             if len(pending) >= max(1, int(patch_batch)):
                 flush()
@@ -157,11 +255,11 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
             if rank != 0:
                 return {'Vp': None, 'Np': None, 'V_updated': None, 'n_patches': n_patches, 'angle1': None,
                         'angle2': None}
-        c = centroid.reshape(-1).tolist()
         L.call('geobi_patch_finalize', L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), V, F, scale, c[0], c[1], c[2], L.stream())
 
     dd = torch.nn.functional.normalize(pts, dim=1) if data_type in ('Kinect_v1', 'Kinect_v2') else None
-    vf = meshprep.vf_padded(rowptr, lst, V)
+    if vf is None:
+        vf = meshprep.vf_padded(rowptr, lst, V)
     Vu = update_position2(Vp, fv, vf, Np, n_iter=n_iter, depth_direction=dd)
     out = {'Vp': Vp, 'Np': Np, 'V_updated': Vu, 'n_patches': n_patches, 'angle1': None, 'angle2': None}
     if gt_points is not None:
@@ -170,4 +268,5 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
         Nt = computer_face_normal(gt, fv)
         out['angle1'] = float(network.error_n(Np, Nt))
         out['angle2'] = float(network.error_n(computer_face_normal(Vu, fv), Nt))
+    ph.tick('merge+update')
     return out

@@ -57,6 +57,12 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
+            # a state dict of torch.optim.Adam carries its options along: the ones that change the update rule must not be
+            # dropped silently (this kernel implements the plain rule the reference uses, train_dual.py:162)
+            for flag in ('amsgrad', 'maximize'):
+                if group.get(flag):
+                    raise ValueError('FlatAdam implements plain Adam: the loaded options ask for %s=True '
+                                     '(use torch.optim.Adam for that state dict)' % flag)
             b1, b2 = group['betas']
             for p in group['params']:
                 g = p.grad

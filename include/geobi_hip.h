@@ -10,9 +10,9 @@
  *   - every pointer is a BORROWED device pointer (HBM) unless marked `host`; the library never
  *     allocates, frees or synchronises: scratch comes in through `ws` / `ws_bytes` (query the size
  *     with the matching *_ws_bytes function, which is a pure host computation + rocPRIM size query).
- *     Three documented exceptions: geobi_read_i32 (the size read-back: waits for `stream`), the whole-network
+ *     Two documented exceptions (plus one helper): geobi_read_i32 (the size read-back: waits for `stream`), the whole-network
  *     entry points geobi_net_forward / geobi_net_forward_train / geobi_net_train_groups (four reads of pooling sizes
- *     per pass, through mapped host memory) and geobi_patch_grow_host (an ordered traversal over HOST arrays)
+ *     per pass, through mapped host memory) -- and, for its own purpose, geobi_host_mailbox (hands out mapped HOST memory)
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
  *   - return value 0 = ok, non-zero = error; the message is in geobi_last_error() (thread-local)
  *   - node features are row-major fp32; indices inside the library are int32.  Per call and graph level at most
@@ -316,19 +316,35 @@ int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row,
 /* ---------------------------------------------------------------- patch split / merge ----
  * Meshes with more faces than one pass takes are cut into overlapping patches, denoised patch by patch
  * and merged (code/dataset.py:156-193, code/test_dual.py:49-61).
- *   geobi_patch_grow_host  HOST function over HOST arrays (the only one in this header): face-ring growth
- *                          from `seed` until neighbor_count faces (<= 0: unlimited) or ring_count rings
- *                          (<= 0: unlimited) are collected, in the visiting order of
- *                          data_util.mesh_get_neighbor_np (code/data_util.py:55-84); vf as CSR, walked in
- *                          list order.  out has room for min(neighbor_count, F) + a ring's overshoot = F ids.
+ *   geobi_patch_grow       data_util.mesh_get_neighbor_np (code/data_util.py:55-84) on the device: face-ring growth from
+ *                          a seed until neighbor_count faces (<= 0: unlimited) or ring_count rings (<= 0: unlimited) are
+ *                          listed, in the reference's visiting order (ring faces in order, their vertices in order, each
+ *                          vertex's incident faces in the order of its row of `vf`, the padded [V, maxval] incidence table
+ *                          of geobi_vf_padded) -- one launch of one workgroup per patch, ring by ring; a
+ *                          vertex is expanded where it is first met, a face met by several expanding (face, vertex,
+ *                          incidence) slots of a ring is listed where the smallest slot meets it.
+ *                          `state`: geobi_patch_grow_state_ints(F, V) int32 set up by geobi_patch_grow_init (which also picks
+ *                          the first seed: the face with the largest d2, lowest id on ties -- code/dataset.py:159); it
+ *                          carries the visited flags from patch to patch.  seed < 0: the seed the previous call picked
+ *                          (pick_next != 0: the unvisited face with the largest d2, code/dataset.py:186-190), so a CHAIN
+ *                          of launches splits a mesh with no host step in between; patch_id: 1, 2, ... (distinct per
+ *                          patch of one split).  sel_out: room for min(neighbor_count, F) ids; n_out (device, optional)
+ *                          and mailbox (mapped host int32, optional: 1 + 2 n, written last) receive the face count; 0
+ *                          faces = every face had been visited.
  *   geobi_submesh          data_util.get_submesh (code/data_util.py:318-336) on the device: sel [n_sel]
  *                          face ids -> v_idx (original vertex ids in first-use order; capacity
  *                          min(V, 3 n_sel)), f_sub [n_sel,3] renumbered faces, count (device int) = number
  *                          of patch vertices.
  *   geobi_patch_accumulate Vp[v_idx] += vert_p, sum_v[v_idx] += 1, Np[f_idx] += norm_p
  *   geobi_patch_finalize   Vp = Vp / sum_v / scale + centroid; Np = normalize(Np) (eps 1e-12)            */
-int geobi_patch_grow_host(const int32_t* fv, const int32_t* vf_rowptr, const int32_t* vf_list, int64_t F,
-                          int64_t seed, int64_t neighbor_count, int64_t ring_count, int32_t* out, int64_t* out_n);
+size_t geobi_patch_grow_state_ints(int64_t F, int64_t V);
+int geobi_patch_grow_init(int32_t* state, int64_t F, int64_t V, const float* d2, void* stream);
+int geobi_patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F, int64_t V, const float* d2, int64_t seed,
+                     int64_t neighbor_count, int64_t ring_count, int patch_id, int32_t* state, int32_t* sel_out,
+                     int32_t* n_out, int32_t* mailbox, int pick_next, void* stream);
+/* n zeroed int32 slots of mapped HOST memory that a kernel can write (the patch sizes above); per host thread, valid until
+ * that thread asks for more slots */
+int geobi_host_mailbox(int n, int32_t** host_ptr);
 size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V);
 int geobi_submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
                   int32_t* count, void* ws, size_t ws_bytes, void* stream);
@@ -414,6 +430,12 @@ int geobi_net_forward_train(const geobi_net_params_t* prm, const geobi_level0_t*
 int geobi_net_backward(int64_t handle, const float* g_verts, const float* g_normals, const geobi_net_params_t* grads,
                        int accumulate, const int32_t* corner_segptr, const int32_t* corner_members, void* stream);
 int geobi_net_release(int64_t handle);
+/* Data-parallel overlap hook: the NEXT geobi_net_backward of the calling host thread records ev_main (on `stream`) and
+ * ev_side (on the library's side stream, where that backward's weight-gradient products run; NULL: not wanted) at the
+ * point where every gradient of gnn_f / fc_f1 / fc_f2 has been enqueued -- the facet branch's backward runs first.  A
+ * caller that waits for both events on its communication stream can all-reduce that half of the gradient bucket under
+ * the vertex branch's backward (hipEvent_t handles passed as void*; one-shot: cleared once recorded).              */
+int geobi_net_backward_facet_events(void* ev_main, void* ev_side);
 /* how often a pooling-size wait ran into its spin cap and fell back to the blocking read (diagnostic; 0 on a healthy run) */
 int geobi_net_spin_cap_hits(void);
 
@@ -485,6 +507,10 @@ int geobi_side_join(void* stream);
  * flop count 2*M*N*K instead and the tag is 1 for gemm_nn (+ its split-K reduce), 2 for gemm_tn
  * (+ its slab reduce).                                                                            */
 int geobi_prof_enable(int kernel);
+/* diagnostic: y[i] = the kernels' own exp for the softmax (csrc/feast_dev.h: exp_le0, six instructions; arguments are
+ * differences to the row maximum, i.e. FINITE and <= 0: <= 2 ulp against exp, results below 2^-126 flush to 0; a
+ * non-finite argument is outside its contract).  Exposed so that a test can check it in isolation.              */
+int geobi_debug_exp_le0(const float* x, float* y, int64_t n, void* stream);
 int geobi_prof_collect(int tag, int64_t* launches, double* total_ms, double* total_bytes);
 
 #ifdef __cplusplus

@@ -202,3 +202,38 @@ def test_two_host_threads_drive_the_library_at_once(dev):
     assert not errs, errs
     for k in range(2):
         assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1])
+
+
+def test_backward_marks_where_the_facet_half_is_final(dev):
+    """geobi_net_backward_facet_events: the backward records the two events once the facet branch's gradients are enqueued;
+    reducing the bucket in two halves behind them (parallel.GradBucket.all_reduce_mean_split) leaves the same gradient."""
+    from geobi_gnn_amd import executor
+    from geobi_gnn_amd.parallel import batched_losses
+    net, bucket, pairs = _setup(dev)
+    dv, df = _union(pairs, [0, 1], dev)
+    _, _, _, _, g_ref = _union_step(net, bucket, dv, df)
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    for e in evs:
+        e.record()
+    torch.cuda.synchronize()
+    off = bucket.facet_offset(net)
+    assert off == sum(p.numel() for k, p in net.named_parameters() if k.startswith(('gnn_v.', 'fc_v')))
+    bucket.zero()
+    vp, npred, _ = net((dv.shallow_copy(), df.shallow_copy()))
+    lv, ln = batched_losses(vp, npred, dv, df, 'L1', 'L1')
+    executor.FACET_EVENTS = evs
+    try:
+        (lv + ln).backward()
+    finally:
+        executor.FACET_EVENTS = None
+    # a stream that only waits for the two events sees the facet half final
+    comm = torch.cuda.Stream(device=dev)
+    for e in evs:
+        comm.wait_event(e)
+    with torch.cuda.stream(comm):
+        tail = bucket.flat[off:].clone()
+    comm.synchronize()
+    assert torch.equal(tail, g_ref[off:])
+    torch.cuda.synchronize()
+    assert torch.equal(bucket.flat, g_ref)
+    assert bucket.all_reduce_mean_split(off, evs, comm) is bucket.flat          # world size 1: nothing to reduce

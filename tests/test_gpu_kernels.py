@@ -612,3 +612,26 @@ def test_match_coarsen_equals_separate_calls(dev, n, m):
         assert torch.equal(cl2, cluster) and torch.equal(cnew2, cnew)
         assert torch.equal(sidx.segptr[:nc + 1], ref.segptr[:nc + 1])
         assert torch.equal(sidx.members, ref.members)
+
+
+def test_softmax_exp_against_fp64(dev):
+    """feast_dev.h: exp_le0, the six-instruction exp of every softmax (arguments: differences to the row maximum, finite
+    and <= 0), checked in isolation through geobi_debug_exp_le0: <= 2 ulp of the fp32 result where it is a normal number,
+    and a flush to zero (never garbage) below 2^-126."""
+    import numpy as np
+    from geobi_gnn_amd import _lib as L
+    xs = np.concatenate([np.linspace(-104.0, 0.0, 200001), -np.logspace(-30, 2, 4001), [0.0, -0.0, -87.33, -87.34, -103.9]])
+    x = torch.tensor(xs[xs >= -104.0], dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    L.call('geobi_debug_exp_le0', L.ptr(x), L.ptr(y), x.numel(), L.stream())
+    want = torch.exp(x.double().cpu())
+    got = y.double().cpu()
+    tiny = 2.0 ** -126
+    normal = want >= tiny
+    ulp = torch.tensor(np.spacing(want[normal].float().numpy()), dtype=torch.float64)
+    err = (got[normal] - want[normal]).abs() / ulp
+    assert float(err.max()) <= 2.0, float(err.max())
+    # below the normal range the hardware exp2 flushes: the result is 0 or the true (denormal) value, never more than 2^-126 off
+    assert float((got[~normal] - want[~normal]).abs().max()) <= tiny
+    assert float(got[~normal].min()) >= 0.0 and bool(torch.isfinite(got).all())
+    assert float(got[x.cpu() == 0].min()) == 1.0

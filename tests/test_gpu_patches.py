@@ -33,6 +33,117 @@ def test_split_matches_reference_fixture(dev):
         vo += nv
 
 
+def _host_incidence(faces, V):
+    from geobi_gnn_amd import meshgen
+    vf = meshgen.vertex_faces(faces.astype(np.int64), V)
+    counts = (vf >= 0).sum(1)
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), vf[vf >= 0].astype(np.int32)
+
+
+def test_device_growth_matches_reference_fixture(dev):
+    """geobi_patch_grow from the fixture's seeds: the face lists of the reference's own mesh_get_neighbor_np, bit for bit;
+    a ring-count-limited growth; an unlimited one."""
+    from geobi_gnn_amd import meshprep, patches
+    fx = load_fixture('patches_n8.npz')
+    fv = torch.from_numpy(fx['faces']).to(dev).int().contiguous()
+    V = fx['points'].shape[0]
+    rowptr, lst = meshprep.vertex_faces(fv, V)
+    vf32 = meshprep.vf_padded32(rowptr, lst, V)
+    off = 0
+    for seed, (nf, nv) in zip(fx['seeds'], fx['sizes']):
+        got = patches.patch_grow(fv, vf32, int(seed), neighbor_count=int(fx['sub_size']))
+        assert np.array_equal(got.cpu().numpy(), fx['select_faces'][off:off + nf])
+        off += nf
+    assert np.array_equal(patches.patch_grow(fv, vf32, 5, ring_count=2).cpu().numpy(), fx['ring2_from_face5'])
+    full = patches.patch_grow(fv, vf32, 0).cpu().numpy()
+    assert full.shape[0] == fv.shape[0] and np.unique(full).shape[0] == fv.shape[0]
+
+
+@pytest.mark.parametrize('freq,sub', [(12, 500), (32, 3000), (45, 20000), (20, 100000)])
+def test_device_split_equals_the_sequential_statement(dev, freq, sub):
+    """The whole split (growth chain + seed selection on the device) against the sequential statement
+    (oracle/mesh_ops.py) on meshes whose rings outgrow one thread's slot chunk and the LDS ring cache's first buffer;
+    sub > F: one patch listing every face."""
+    from geobi_gnn_amd import meshgen, meshprep, patches
+    from oracle import mesh_ops
+    noisy, _, faces = meshgen.noisy_icosphere(freq, 0.2, seed=11)
+    pts = torch.as_tensor(noisy, dtype=torch.float32, device=dev)
+    fv = torch.as_tensor(faces, dtype=torch.int32, device=dev).contiguous()
+    V = pts.shape[0]
+    got = [s.cpu().numpy() for s in patches.split_faces(pts, fv, sub)]
+    # the oracle walks the same incidence order (ascending face ids per vertex) and the same fp32 d2
+    rowptr, lst = _host_incidence(faces, V)
+    centroid = pts.mean(0, keepdim=True)
+    d2 = ((pts[fv.long()].mean(1) - centroid) ** 2).sum(1).cpu().numpy()
+    want = mesh_ops.split_faces(d2, np.ascontiguousarray(faces, dtype=np.int32), rowptr, lst, sub)
+    assert len(got) == len(want)
+    for g, (_, w) in zip(got, want):
+        assert np.array_equal(g, w)
+    # a second split right behind the first (the mailbox and the side stream are reused)
+    again = [s.cpu().numpy() for s in patches.split_faces(pts, fv, sub, ahead=3)]
+    assert len(again) == len(got) and all(np.array_equal(a, g) for a, g in zip(again, got))
+
+
+def _disk_mesh(k, rings):
+    """A triangulated disk: one centre vertex of valence k, `rings` concentric rings of k points (exercises the wider
+    incidence-row instantiations of the growth kernel)."""
+    pts = [(0.0, 0.0, 0.0)]
+    for r in range(1, rings + 1):
+        for i in range(k):
+            a = 2 * np.pi * (i + 0.5 * r) / k
+            pts.append((r * np.cos(a), r * np.sin(a), 0.05 * np.sin(3 * a) * r))
+    faces = []
+    ring = lambda r, i: 1 + (r - 1) * k + (i % k)
+    for i in range(k):
+        faces.append((0, ring(1, i), ring(1, i + 1)))
+    for r in range(1, rings):
+        for i in range(k):
+            faces.append((ring(r, i), ring(r + 1, i), ring(r, i + 1)))
+            faces.append((ring(r, i + 1), ring(r + 1, i), ring(r + 1, i + 1)))
+    return np.asarray(pts, dtype=np.float32), np.asarray(faces, dtype=np.int32)
+
+
+@pytest.mark.parametrize('k,rings,sub', [(12, 6, 40), (20, 8, 150), (40, 5, 90)])
+def test_device_split_on_wide_incidence_rows(dev, k, rings, sub):
+    """Valence 12 / 20 / 40 at the centre: the 16-, 32- and 64-entry instantiations against the sequential statement."""
+    from geobi_gnn_amd import meshprep, patches
+    from oracle import mesh_ops
+    pts_h, faces = _disk_mesh(k, rings)
+    pts = torch.from_numpy(pts_h).to(dev)
+    fv = torch.from_numpy(faces).to(dev).contiguous()
+    V = pts.shape[0]
+    rowptr, lst = meshprep.vertex_faces(fv, V)
+    assert int(meshprep.vf_padded32(rowptr, lst, V).shape[1]) == k
+    got = [s.cpu().numpy() for s in patches.split_faces(pts, fv, sub)]
+    rp, ls = _host_incidence(faces, V)
+    centroid = pts.mean(0, keepdim=True)
+    d2 = ((pts[fv.long()].mean(1) - centroid) ** 2).sum(1).cpu().numpy()
+    want = mesh_ops.split_faces(d2, faces, rp, ls, sub)
+    assert len(got) == len(want)
+    for g, (_, w) in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_device_split_beyond_the_lds_bitmaps(dev):
+    """More faces / vertices than the kernel's LDS bitmaps hold (n = 115: 264 500 faces, 132 252 vertices): the
+    instantiation with per-patch stamps in HBM."""
+    from geobi_gnn_amd import meshgen, patches
+    from oracle import mesh_ops
+    noisy, _, faces = meshgen.noisy_icosphere(115, 0.2, seed=3)
+    pts = torch.as_tensor(noisy, dtype=torch.float32, device=dev)
+    fv = torch.as_tensor(faces, dtype=torch.int32, device=dev).contiguous()
+    V = pts.shape[0]
+    assert fv.shape[0] > 262144 and V > 131072
+    got = [s.cpu().numpy() for s in patches.split_faces(pts, fv, 60000)]
+    rp, ls = _host_incidence(faces, V)
+    centroid = pts.mean(0, keepdim=True)
+    d2 = ((pts[fv.long()].mean(1) - centroid) ** 2).sum(1).cpu().numpy()
+    want = mesh_ops.split_faces(d2, np.ascontiguousarray(faces, dtype=np.int32), rp, ls, 60000)
+    assert len(got) == len(want)
+    for g, (_, w) in zip(got, want):
+        assert np.array_equal(g, w)
+
+
 def test_predict_mesh_merges_like_the_reference(dev):
     """test_dual.py:49-61 restated with torch indexing beside the device merge."""
     from geobi_gnn_amd import meshprep, network, patches

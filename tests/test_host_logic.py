@@ -141,6 +141,18 @@ for i, p in enumerate(net.parameters()):
 flat = bucket.all_reduce_mean()
 for i, p in enumerate(net.parameters()):
     assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5 * (i + 1))), i
+# the facet half first, then the vertex half (what runs under the vertex branch's backward on the MI355X): the same bucket
+g0 = torch.Generator().manual_seed(17 + rank)
+mine = torch.randn(bucket.flat.numel(), generator=g0)
+bucket.flat.copy_(mine)
+one_shot = bucket.all_reduce_mean().clone()
+bucket.flat.copy_(mine)
+off = bucket.facet_offset(net)
+assert 0 < off < bucket.flat.numel() and off == sum(p.numel() for k, p in net.named_parameters()
+                                                      if k.startswith(('gnn_v.', 'fc_v')))
+assert torch.equal(bucket.all_reduce_mean_split(off), one_shot)
+for i, p in enumerate(net.parameters()):
+    p.grad.fill_(1.5 * (i + 1))
 # the optimiser sees the reduced gradients through the same views
 opt = torch.optim.SGD(net.parameters(), lr=1.0)
 before = net.fc_f2.bias.detach().clone()
@@ -308,9 +320,11 @@ def test_op_tape_matches_autograd_on_a_dag():
 
 
 def test_patch_growth_matches_reference_fixture():
-    """geobi_patch_grow_host (a HOST function of the C ABI) against face lists produced by the reference's
-    own data_util.mesh_get_neighbor_np (tests/golden/patches_n8.npz, oracle/gen_golden.py:gen_patches)."""
-    from geobi_gnn_amd import meshgen, patches
+    """The sequential statement of the ring growth (oracle/oracle_c.c: oracle_patch_grow, the spec of the device kernel
+    geobi_patch_grow) against face lists produced by the reference's own data_util.mesh_get_neighbor_np
+    (tests/golden/patches_n8.npz, oracle/gen_golden.py:gen_patches), and the seed loop of dataset.py:156-193 around it."""
+    from geobi_gnn_amd import meshgen
+    from oracle import mesh_ops
     from helpers import load_fixture
     fx = load_fixture('patches_n8.npz')
     faces = fx['faces']
@@ -322,13 +336,19 @@ def test_patch_growth_matches_reference_fixture():
     fv = np.ascontiguousarray(faces, dtype=np.int32)
     off = 0
     for seed, (nf, nv) in zip(fx['seeds'], fx['sizes']):
-        got = patches.patch_grow(fv, rowptr, lst, int(seed), neighbor_count=int(fx['sub_size']))
+        got = mesh_ops.patch_grow(fv, rowptr, lst, int(seed), neighbor_count=int(fx['sub_size']))
         assert np.array_equal(got, fx['select_faces'][off:off + nf])
         off += nf
-    assert np.array_equal(patches.patch_grow(fv, rowptr, lst, 5, ring_count=2), fx['ring2_from_face5'])
+    assert np.array_equal(mesh_ops.patch_grow(fv, rowptr, lst, 5, ring_count=2), fx['ring2_from_face5'])
     # unlimited growth reaches every face of the (connected) sphere exactly once
-    full = patches.patch_grow(fv, rowptr, lst, 0)
+    full = mesh_ops.patch_grow(fv, rowptr, lst, 0)
     assert full.shape[0] == faces.shape[0] and np.unique(full).shape[0] == faces.shape[0]
+    # the seed loop: same seeds, same patches as the reference's split
+    pts = fx['points'].astype(np.float32)
+    d2 = ((pts[faces].mean(1) - pts.mean(0, keepdims=True)) ** 2).sum(1)
+    split = mesh_ops.split_faces(d2, fv, rowptr, lst, int(fx['sub_size']))
+    assert [s for s, _ in split] == [int(s) for s in fx['seeds']]
+    assert np.array_equal(np.concatenate([f for _, f in split]), fx['select_faces'])
 
 
 def test_processed_file_round_trip(tmp_path):
@@ -551,3 +571,18 @@ def test_sizes_beyond_the_documented_limits_are_rejected():
     rc = lib.geobi_net_forward(ctypes.byref(prm), ctypes.byref(big), ctypes.byref(ok), one, one, one, None, one, 1 << 20,
                                ctypes.byref(out), None)
     assert rc != 0 and b'GEOBI_MAX_NODES' in lib.geobi_last_error()
+
+
+def test_flat_adam_refuses_options_it_does_not_implement():
+    """a state dict of Adam(amsgrad=True) / Adam(maximize=True) loads into FlatAdam (same layout) but must not
+    train with another update rule silently."""
+    import pytest
+    from geobi_gnn_amd.train_util import FlatAdam
+    for kw in ({'amsgrad': True}, {'maximize': True}):
+        p = torch.nn.Parameter(torch.zeros(4))
+        donor = torch.optim.Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3, **kw)
+        opt = FlatAdam([p], lr=1e-3)
+        opt.load_state_dict(donor.state_dict())
+        p.grad = torch.ones(4)
+        with pytest.raises(ValueError, match=list(kw)[0]):
+            opt.step()
