@@ -465,6 +465,17 @@ int geobi_ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf,
   return ring_graph_fill(kind, fv, rowptr_vf, list, n_nodes, rowptr_g, col, S(stream));
 }
 
+size_t geobi_calc_weight_parts_ws_bytes(int n_parts) { return calc_weight_parts_ws_bytes(n_parts); }
+
+int geobi_calc_weight_parts(const float* pos, const float* normal, const int32_t* rowptr, const int32_t* row,
+                            const int32_t* col, int64_t E, const int32_t* node_ptr, int n_parts, float* w, void* ws,
+                            size_t ws_bytes, void* stream) {
+  SIZES(0, E);
+  NOTNULL(pos); NOTNULL(normal); NOTNULL(rowptr); NOTNULL(node_ptr); NOTNULL(ws);
+  if (E > 0) { NOTNULL(row); NOTNULL(col); NOTNULL(w); }
+  return calc_weight_parts(pos, normal, rowptr, row, col, E, node_ptr, n_parts, w, ws, ws_bytes, S(stream));
+}
+
 size_t geobi_calc_weight_ws_bytes(void) { return calc_weight_ws_bytes(); }
 
 int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,

@@ -253,6 +253,9 @@ int ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf, cons
                      int32_t* rowptr_g, void* ws, size_t ws_bytes, hipStream_t s);
 int ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list, int64_t n_nodes,
                     const int32_t* rowptr_g, int32_t* col, hipStream_t s);
+size_t calc_weight_parts_ws_bytes(int n_parts);
+int calc_weight_parts(const float* pos, const float* normal, const int32_t* rowptr, const int32_t* row, const int32_t* col,
+                      int64_t E, const int32_t* node_ptr, int n_parts, float* w, void* ws, size_t ws_bytes, hipStream_t s);
 size_t calc_weight_ws_bytes();
 int calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                 int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, hipStream_t s);

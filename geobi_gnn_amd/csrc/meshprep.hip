@@ -203,6 +203,54 @@ __global__ void calc_weight_kernel(const float* __restrict__ pos, const float* _
   w[e] = dn * expf(len2 / den);
 }
 
+// The same two kernels over a disjoint union of meshes ("parts": node ranges node_ptr[p] .. node_ptr[p+1], whose edges are
+// the CSR rows of those nodes): every part gets ITS OWN mean edge length, formed with the blocking the single-mesh kernels use
+// (block b of the part sums the part's edges b * 256 + t, + 65 536, ...), so a part's weights are the bits the part alone gives.
+__global__ __launch_bounds__(256) void edge_length_partial_parts_kernel(const float* __restrict__ pos,
+                                                                        const int* __restrict__ rowptr,
+                                                                        const int* __restrict__ row,
+                                                                        const int* __restrict__ col,
+                                                                        const int* __restrict__ node_ptr,
+                                                                        double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int part = blockIdx.y;
+  const int64_t e0 = rowptr[node_ptr[part]], E = (int64_t)rowptr[node_ptr[part + 1]] - e0;
+  double s = 0.0;
+  for (int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x; el < E; el += (int64_t)gridDim.x * 256) {
+    const int64_t e = e0 + el;
+    const int i = row[e], j = col[e];
+    const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+    s += (double)sqrtf((dx * dx + dy * dy) + dz * dz);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)part * kPartials + blockIdx.x] = red[0];
+}
+
+__global__ void calc_weight_parts_kernel(const float* __restrict__ pos, const float* __restrict__ nrm,
+                                         const int* __restrict__ rowptr, const int* __restrict__ row,
+                                         const int* __restrict__ col, int64_t E, const int* __restrict__ node_ptr, int n_parts,
+                                         const double* __restrict__ partial, float* __restrict__ w) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int i = row[e], j = col[e];
+  int part = 0;
+  while (part + 1 < n_parts && i >= node_ptr[part + 1]) ++part;
+  const int a = node_ptr[part], b = node_ptr[part + 1];
+  const int64_t denom = ((int64_t)rowptr[b] - rowptr[a]) + (b - a);        // the part's edges + one zero-length loop per node
+  const float mean = mean_from_partials(partial + (size_t)part * kPartials, denom);
+  const float den = -2.0f * mean + 1e-12f;
+  const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+  const float len2 = (dx * dx + dy * dy) + dz * dz;
+  float dn = (nrm[3 * i] * nrm[3 * j] + nrm[3 * i + 1] * nrm[3 * j + 1]) + nrm[3 * i + 2] * nrm[3 * j + 2];
+  dn = dn > 0.001f ? dn : 0.001f;
+  w[e] = dn * expf(len2 / den);
+}
+
 }  // namespace
 
 size_t vertex_faces_ws_bytes(int64_t F, int64_t V) {
@@ -312,6 +360,22 @@ int calc_weight(const float* pos, const float* normal, const int32_t* row, const
     calc_weight_kernel<<<cdiv(E, 256), 256, 0, s>>>(pos, normal, row, col, E, partial, denom, w);
     GEOBI_LAUNCH_OK();
   }
+  return 0;
+}
+
+size_t calc_weight_parts_ws_bytes(int n_parts) { return align_up((size_t)(n_parts > 0 ? n_parts : 1) * kPartials * sizeof(double)) + 256; }
+
+int calc_weight_parts(const float* pos, const float* normal, const int32_t* rowptr, const int32_t* row, const int32_t* col,
+                      int64_t E, const int32_t* node_ptr, int n_parts, float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+  GEOBI_REQUIRE(n_parts > 0 && n_parts <= 4096, "calc_weight_parts: 1 .. 4096 parts (got %d)", n_parts);
+  Arena a(ws, ws_bytes);
+  double* partial = a.take<double>((size_t)n_parts * kPartials);
+  GEOBI_REQUIRE(a.ok() && partial, "calc_weight_parts: workspace too small");
+  if (E <= 0) return 0;
+  edge_length_partial_parts_kernel<<<dim3(kPartials, n_parts), 256, 0, s>>>(pos, rowptr, row, col, node_ptr, partial);
+  GEOBI_LAUNCH_OK();
+  calc_weight_parts_kernel<<<cdiv(E, 256), 256, 0, s>>>(pos, normal, rowptr, row, col, E, node_ptr, n_parts, partial, w);
+  GEOBI_LAUNCH_OK();
   return 0;
 }
 

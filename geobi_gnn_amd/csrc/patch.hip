@@ -100,7 +100,7 @@ __global__ void patch_finalize_kernel(float* __restrict__ Vp, float* __restrict_
 // incidence loads of a ring 11 k cycles, their hash inserts 11 k, append 5 k, barriers 3 k of 37 k per ring); the host
 // loop it replaces 0.37 ms.
 constexpr int kGrowThreads = 1024;
-constexpr int kGrowRingLds = 2048;        // ring faces whose vertex rows are kept in LDS (2 buffers x 24 KB)
+constexpr int kGrowRingLds = 2048;        // ring faces whose vertex rows (24 KB) and ids (8 KB) are kept in LDS
 constexpr int kGrowIter = 4;              // items per lane and pass
 constexpr int kGrowIter2 = 8;             // (vertex, entry) slots per lane and pass
 constexpr int kGrowWinners = 2048;        // expanding vertices a pass lists
@@ -110,7 +110,8 @@ constexpr int kGrowFaceBits = 262144, kGrowVertBits = 131072; // 32 KB + 16 KB o
 
 // dynamic LDS layout (ints)
 constexpr int kOffFv = 0;
-constexpr int kOffFaceTab = kOffFv + 2 * 3 * kGrowRingLds;
+constexpr int kOffIds = kOffFv + 3 * kGrowRingLds;       // the ring being appended: face ids (their rows follow at the ring's end)
+constexpr int kOffFaceTab = kOffIds + kGrowRingLds;
 constexpr int kOffVertTab = kOffFaceTab + 2 * kGrowFaceTab;
 constexpr int kOffWinners = kOffVertTab + 2 * kGrowVertTab;
 constexpr int kOffFaceBits = kOffWinners + kGrowWinners;
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
     int* __restrict__ visited, int* __restrict__ state, int* __restrict__ sel_out, int* __restrict__ n_out, int* mailbox,
     int pick_next) {
   extern __shared__ int s_dyn[];
-  int* s_fv = s_dyn + kOffFv;                         // [2][3 * kGrowRingLds]
+  int* s_fv = s_dyn + kOffFv;                         // [3 * kGrowRingLds] vertex rows of the ring being walked
+  int* s_ids = s_dyn + kOffIds;                       // [kGrowRingLds] ids of the ring being appended
   int* ft_id = s_dyn + kOffFaceTab;                   // face table
   int* ft_val = ft_id + kGrowFaceTab;
   int* vt_id = s_dyn + kOffVertTab;                   // vertex table
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
     }
     (void)mine;
   };
-  int n = 1, ring_start = 0, ring_end = 1, cur = 0;
+  int n = 1, ring_start = 0, ring_end = 1;
+  bool need_clear = true;                             // the tables are cleared by the lanes that used them; in full only here and after a redone pass
   if (t == 0) {
     sel_out[0] = seed; visited[seed] = 1;
     if (LDSBITS) atomicOr(&fbits[seed >> 5], 1u << (seed & 31)); else stamp[seed] = patch_id;
@@ -257,8 +260,7 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
   for (int ring = 0; ring < ring_count && n < neighbor_count; ++ring) {
     const int R = ring_end - ring_start;
     const long long items = 3ll * R;
-    const int* ring_fv = s_fv + cur * 3 * kGrowRingLds;
-    int* next_fv = s_fv + (cur ^ 1) * 3 * kGrowRingLds;
+    const int* ring_fv = s_fv;
     int added = 0;                                                // faces this ring has appended so far (uniform)
     // items of one pass: the whole ring when it fits (spread over the waves), halved whenever a pass overflows a table
     long long pass_items = items < (long long)kGrowThreads * kGrowIter ? items : (long long)kGrowThreads * kGrowIter;
@@ -266,10 +268,13 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
     while (pass0 < items && n < neighbor_count) {
       const long long pass_end = pass0 + pass_items < items ? pass0 + pass_items : items;
       const int it1 = (int)((pass_end - pass0 + kGrowThreads - 1) / kGrowThreads);
-      for (int i = t; i < kGrowFaceTab; i += kGrowThreads) { ft_id[i] = -1; ft_val[i] = 0x7fffffff; }
-      for (int i = t; i < kGrowVertTab; i += kGrowThreads) { vt_id[i] = -1; vt_val[i] = 0x7fffffff; }
-      if (t == 0) { s_full[0] = 0; s_full[1] = 0; }
-      __syncthreads();
+      if (need_clear) {
+        for (int i = t; i < kGrowFaceTab; i += kGrowThreads) { ft_id[i] = -1; ft_val[i] = 0x7fffffff; }
+        for (int i = t; i < kGrowVertTab; i += kGrowThreads) { vt_id[i] = -1; vt_val[i] = 0x7fffffff; }
+        if (t == 0) { s_full[0] = 0; s_full[1] = 0; }
+        __syncthreads();
+        need_clear = false;
+      }
       // ---- 1: the item's vertex; unexpanded vertices enter the vertex table with their item number
       const long long base = pass0 + (long long)wave * (64 * it1) + lane;
       int vtx[kGrowIter], vh[kGrowIter];
@@ -306,12 +311,14 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
       if (s_full[1] || nw > kGrowWinners || slots > (long long)kGrowThreads * kGrowIter2) {   // too much for one pass
         __syncthreads();
         pass_items = pass_items > 1 ? pass_items / 2 : 1;        // one item expands at most W <= 8192 slots: always fits
+        need_clear = true;
         continue;
       }
       {
         int running = woff;
 #pragma unroll
         for (int i = 0; i < kGrowIter; ++i) {
+          if (vh[i] >= 0) { vt_id[vh[i]] = -1; vt_val[vh[i]] = 0x7fffffff; }       // every reader is past the barrier above
           if ((fm[i] >> lane) & 1ull) {
             wl[running + __popcll(fm[i] & lt_mask)] = vtx[i];
             if (LDSBITS) atomicOr(&vbits[vtx[i] >> 5], 1u << (vtx[i] & 31)); else vstamp[vtx[i]] = patch_id;
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
         }
         __syncthreads();
         pass_items = pass_items > 1 ? pass_items / 2 : 1;
+        need_clear = true;
         continue;
       }
       // ---- 3: winners in slot order -> positions
@@ -367,26 +375,36 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
       __syncthreads();
       int total;
       wave_offsets(cnt, woff, total);
-      // ---- 4: append
+      // ---- 4: append (ids also into LDS: the ring's end fetches the rows from there, so nothing in this kernel waits for
+      //         the global stores below)
       const int room = neighbor_count - n;
       const int take = total < room ? total : room;
+      const bool ids_lds = added + take <= kGrowRingLds;
       {
         int running = woff;
 #pragma unroll
         for (int i = 0; i < kGrowIter2; ++i) {
+          if (fh[i] >= 0) { ft_id[fh[i]] = -1; ft_val[fh[i]] = 0x7fffffff; }        // every reader is past the barrier above
           if ((wm[i] >> lane) & 1ull) {
             const int idx = running + __popcll(wm[i] & lt_mask);
             if (idx < room) {
               const int g = gg[i];
               sel_out[n + idx] = g;
               visited[g] = 1;
+              if (ids_lds) s_ids[added + idx] = g;
               if (LDSBITS) atomicOr(&fbits[g >> 5], 1u << (g & 31)); else stamp[g] = patch_id;
             }
           }
           running += __popcll(wm[i]);
         }
       }
-      __syncthreads();
+      if (LDSBITS) {                                              // LDS traffic only: no need to drain the stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      } else {
+        __syncthreads();
+      }
       n += take;
       added += take;
       pass0 = pass_end;
@@ -394,18 +412,16 @@ __global__ __launch_bounds__(kGrowThreads) void patch_grow_kernel(
     ring_lds = added <= kGrowRingLds;
     ring_start = ring_end;
     ring_end = n;
-    cur ^= 1;
     if (ring_start == ring_end) break;
     if (ring_lds) {
-      // the new ring's vertex rows into LDS, one face per thread and step: the ids were just listed (cache-hot), the rows are
-      // ONE round trip for the whole ring
+      // the new ring's vertex rows into LDS, one face per thread and step: ONE round trip for the whole ring
       for (int j = t; j < added; j += kGrowThreads) {
-        const int g = sel_out[ring_start + j];
-        int* row = next_fv + 3 * j;
+        const int g = s_ids[j];
+        int* row = s_fv + 3 * j;
         row[0] = fv[3 * (size_t)g]; row[1] = fv[3 * (size_t)g + 1]; row[2] = fv[3 * (size_t)g + 2];
       }
-      __syncthreads();
     }
+    __syncthreads();                                              // rows parked; sel_out / stamps visible for the global forms
   }
   __syncthreads();
   if (pick_next) grow_pick_seed(d2, visited, F, state, s_dyn);    // the tables are dead: their LDS is the scratch

@@ -126,14 +126,29 @@ def _reference_coo(graph, weight, normal, loops_inline):
     return torch.stack([r, c], 0), w
 
 
+def calc_weight_parts(pos, normal, graph, node_ptr):
+    """calc_weight over a disjoint union of meshes: ``node_ptr`` (device int32 [P+1]) cuts the nodes into parts and every
+    part is normalised by ITS OWN mean edge length (geobi_calc_weight_parts: bit-identical to the part alone)."""
+    dev = pos.device
+    n_parts = int(node_ptr.numel()) - 1
+    w = torch.empty(max(graph.E, 1), dtype=torch.float32, device=dev)[:graph.E]
+    ws = L.workspace(L.size_query('geobi_calc_weight_parts_ws_bytes', n_parts), dev)
+    L.call('geobi_calc_weight_parts', L.ptr(pos), L.ptr(normal), L.ptr(graph.rowptr_out), L.ptr(graph.ensure_rows()),
+           L.ptr(graph.col_out), graph.E, L.ptr(node_ptr), n_parts, L.ptr(w), L.ptr(ws), ws.numel(), L.stream())
+    return w
+
+
 def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type='Synthetic', device=None,
-                    reference_layout=False, centroid=None, scale=None, trusted_faces=False, want_vf=True):
+                    reference_layout=False, centroid=None, scale=None, trusted_faces=False, want_vf=True, parts=None):
     """(points [V,3], faces [F,3]) -> (data_v, data_f) as process_one_submesh + post_processing emit them,
     computed on the device.  Same fields as ``meshgen.build_dual_data`` (incl. ``data_v.meta``).
     ``centroid`` [1,3] / ``scale``: normalisation of the WHOLE mesh when this is one patch of it
     (dataset.py:177-178 overwrite the patch's own values).
     trusted_faces: the face table was produced by this library (a patch of geobi_submesh): no range check.
-    want_vf=False: no padded vf table in ``data_v.meta`` (a patch is never vertex-updated on its own)."""
+    want_vf=False: no padded vf table in ``data_v.meta`` (a patch is never vertex-updated on its own).
+    parts: (vertex_ptr, face_ptr) host int lists when the input is a DISJOINT UNION of meshes (the patches of one network
+    pass, vertices / faces of part k in [ptr[k], ptr[k+1])): one preprocessing for all of them -- every step is local to a
+    connected component except the bilateral weights' mean edge length, which is taken per part; ``mesh_ptr`` is set."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     if not torch.cuda.is_available():
         raise L.GeobiError('meshprep.build_dual_data runs on the MI355X only (no CPU fallback); '
@@ -158,12 +173,12 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
         ws = L.workspace(L.size_query('geobi_ring_graph_ws_bytes', n), dev)
         L.call('geobi_ring_graph_count', kind, L.ptr(fv), L.ptr(rowptr_vf), L.ptr(lst), n, L.ptr(rp), L.ptr(ws), ws.numel(),
                L.stream())
-    parts = [rp_v[V:V + 1], rp_f[F:F + 1]]
+    size_words = [rp_v[V:V + 1], rp_f[F:F + 1]]
     if want_vf:
         m = torch.zeros(1, dtype=torch.int32, device=dev)
         L.call('geobi_max_degree', L.ptr(rowptr_vf), V, L.ptr(m), L.stream())
-        parts.append(m)
-    sizes = L.read_i32(torch.cat(parts))
+        size_words.append(m)
+    sizes = L.read_i32(torch.cat(size_words))
     E_v, E_f = sizes[0], sizes[1]
 
     def finish_graph(kind, n, rp, E):
@@ -184,8 +199,14 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
         cen = torch.as_tensor(centroid, dtype=torch.float32).reshape(1, 3).to(dev)
     sc = float((1.0 / mean_edge_length(pts, g_v)).item()) if scale is None else float(scale)
 
-    ew_v = calc_weight(pts, vn, g_v)
-    ew_f = calc_weight(pos_f, fn, g_f)
+    if parts is None:
+        ew_v = calc_weight(pts, vn, g_v)
+        ew_f = calc_weight(pos_f, fn, g_f)
+    else:
+        ptr_dev = torch.tensor(list(parts[0]) + list(parts[1]), dtype=torch.int32).to(dev, non_blocking=True)
+        nvp = len(parts[0])
+        ew_v = calc_weight_parts(pts, vn, g_v, ptr_dev[:nvp])
+        ew_f = calc_weight_parts(pos_f, fn, g_f, ptr_dev[nvp:])
 
     data_v = Data(torch.cat(((pts - cen) * sc, vn), 1), None, name=name + '-v')
     data_f = Data(torch.cat(((pos_f - cen) * sc, fn), 1), None, fv_indices=fv.long(), name=name + '-f')
@@ -217,4 +238,7 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
         L.call('geobi_vf_padded', L.ptr(rowptr_vf), L.ptr(lst), V, maxval, L.ptr(vf), L.stream())
         vf = vf.long()
     data_v.meta = {'centroid': cen, 'scale': sc, 'vf_indices': vf, 'incidence': (rowptr_vf, lst)}
+    if parts is not None:
+        data_v.mesh_ptr = torch.tensor(list(parts[0]), dtype=torch.long)
+        data_f.mesh_ptr = torch.tensor(list(parts[1]), dtype=torch.long)
     return data_v, data_f

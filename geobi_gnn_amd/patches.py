@@ -49,8 +49,8 @@ def patch_grow(fv, vf32, seed, neighbor_count=None, ring_count=None):
     return out[:L.read_i32(n, 1)[0]]
 
 
-def submesh(fv, sel, num_vertices):
-    """data_util.get_submesh on the device: sel [n] int32 face ids -> (V_idx [nv] int32, F_sub [n,3] int32)."""
+def _submesh_launch(fv, sel, num_vertices):
+    """geobi_submesh enqueued: (V_idx buffer, F_sub, count [1]) -- the count is still on the device."""
     dev = fv.device
     n, V = int(sel.shape[0]), int(num_vertices)
     v_idx = torch.empty(min(V, 3 * n), dtype=torch.int32, device=dev)
@@ -59,7 +59,43 @@ def submesh(fv, sel, num_vertices):
     ws = L.workspace(L.size_query('geobi_submesh_ws_bytes', n, V), dev)
     L.call('geobi_submesh', L.ptr(fv), L.ptr(sel), n, V, L.ptr(v_idx), L.ptr(f_sub), L.ptr(count), L.ptr(ws),
            ws.numel(), L.stream())
+    return v_idx, f_sub, count
+
+
+def submesh(fv, sel, num_vertices):
+    """data_util.get_submesh on the device: sel [n] int32 face ids -> (V_idx [nv] int32, F_sub [n,3] int32)."""
+    v_idx, f_sub, count = _submesh_launch(fv, sel, num_vertices)
     return v_idx[:L.read_i32(count, 1)[0]], f_sub
+
+
+def build_patch_union(pts, fv, sels, centroid, scale, data_type='Synthetic'):
+    """Several patches (face lists `sels`) of one mesh as ONE preprocessed disjoint-union pair: vertex renumbering of every
+    patch (geobi_submesh) enqueued first and their sizes read TOGETHER, the patches' points and faces concatenated (two
+    geobi_concat32 launches + one gather), then a single pass of meshprep.build_dual_data over the union -- graph
+    construction and normals are local to a component; the bilateral weights take each patch's own mean edge length
+    (geobi_calc_weight_parts), so every patch gets the bits it gets on its own.  What was ~35 small launches and two host
+    reads PER PATCH is that per network pass.
+    -> ((data_v, data_f), [v_idx per patch], vertex ranges, face ranges)"""
+    from .data import _Concat
+    dev, V = fv.device, int(pts.shape[0])
+    subs = [_submesh_launch(fv, sel, V) for sel in sels]
+    counts = L.read_i32(torch.cat([c for _, _, c in subs]))
+    vptr, fptr = [0], [0]
+    for nv, sel in zip(counts, sels):
+        vptr.append(vptr[-1] + nv)
+        fptr.append(fptr[-1] + int(sel.shape[0]))
+    v_idx = [vi[:nv] for (vi, _, _), nv in zip(subs, counts)]
+    if len(sels) == 1:
+        idx_all, faces = v_idx[0], subs[0][1]
+    else:
+        cc = _Concat(dev)
+        idx_all = cc.cat(v_idx)
+        faces = cc.cat([f.view(-1) for _, f, _ in subs], vptr[:-1]).view(-1, 3)
+        cc.run()
+    dual = meshprep.build_dual_data(pts[idx_all.long()], faces, name='patches', data_type=data_type, device=dev,
+                                    centroid=centroid, scale=scale, trusted_faces=True, want_vf=False,
+                                    parts=(vptr, fptr) if len(sels) > 1 else None)
+    return dual, v_idx, list(zip(vptr[:-1], vptr[1:])), list(zip(fptr[:-1], fptr[1:]))
 
 
 def split_faces(points, fv, submesh_size, incidence=None, vf32=None, ahead=None):
@@ -159,7 +195,7 @@ class _Phases(object):
             self.t = now
 
 
-def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=8,
+def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synthetic', gt_points=None, patch_batch=5,
                  distributed=None, stats=None):
     """test_dual.py:24-87 without the OBJ IO, for a mesh of any size: preprocessing, patch split when
     F > sub_size, network, merge, de-normalisation, vertex update -- all device-resident.  The reference runs
@@ -222,31 +258,22 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
         def flush():
             if not pending:
                 return
-            if len(pending) == 1:
-                dual, vr, fr = pending[0][2], [(0, pending[0][1].shape[0])], [(0, pending[0][0].shape[0])]
-            else:
-                dual, vr, fr = _union_dual([p[2] for p in pending])
+            dual, v_idxs, vr, fr = build_patch_union(pts, fv, pending, centroid, scale, data_type)
             ph.tick('preprocessing')
             vert_p, norm_p = predict_one_submesh(net, dual)
             ph.tick('network')
-            for (sel, v_idx, _), (v0, v1), (f0, f1) in zip(pending, vr, fr):
+            for sel, v_idx, (v0, v1), (f0, f1) in zip(pending, v_idxs, vr, fr):
                 L.call('geobi_patch_accumulate', L.ptr(vert_p[v0:v1]), L.ptr(norm_p[f0:f1]), L.ptr(v_idx), L.ptr(sel),
                        v_idx.shape[0], sel.shape[0], L.ptr(Vp), L.ptr(Np), L.ptr(sum_v), L.stream())
             del pending[:]
             ph.tick('merge+update')
 
-        keep = None if world == 1 else (lambda k: parallel.owns_patch(k, rank, world))
-        for part in split_patches(pts, fv, sub_size, incidence=(rowptr, lst), keep=keep, vf32=vf32):
+        for k, sel in enumerate(split_faces(pts, fv, sub_size, incidence=(rowptr, lst), vf32=vf32)):
             n_patches += 1
-            if part is None:
-                continue
-            sel, v_idx, f_sub = part
             ph.tick('growth')
-            dual = meshprep.build_dual_data(pts[v_idx.long()], f_sub, name='patch%d' % (n_patches - 1),
-                                            data_type=data_type, device=dev, centroid=centroid, scale=scale,
-                                            trusted_faces=True, want_vf=False)
-            ph.tick('preprocessing')
-            pending.append((sel, v_idx, dual))
+            if world > 1 and not parallel.owns_patch(k, rank, world):
+                continue
+            pending.append(sel)
             if len(pending) >= max(1, int(patch_batch)):
                 flush()
         flush()

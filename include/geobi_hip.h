@@ -309,6 +309,15 @@ int geobi_ring_graph_count(int kind, const int32_t* fv, const int32_t* rowptr_vf
                            int64_t n_nodes, int32_t* rowptr_g, void* ws, size_t ws_bytes, void* stream);
 int geobi_ring_graph_fill(int kind, const int32_t* fv, const int32_t* rowptr_vf, const int32_t* list,
                           int64_t n_nodes, const int32_t* rowptr_g, int32_t* col, void* stream);
+/* geobi_calc_weight_parts: geobi_calc_weight over a disjoint union of meshes (the patches of one network pass): node_ptr
+ * [n_parts + 1] (device) cuts the nodes into parts, a part's edges are the CSR rows of its nodes, and every part gets its
+ * OWN mean edge length (calc_weight normalises by the mean of the edges it is handed, code/data_util.py:383-398, and the
+ * reference hands it one patch at a time) -- formed in the single-mesh kernel's order, so the weights of a part are
+ * bit-identical to what the part alone gives.  The mean's denominator counts one zero-length self loop per node.        */
+size_t geobi_calc_weight_parts_ws_bytes(int n_parts);
+int geobi_calc_weight_parts(const float* pos, const float* normal, const int32_t* rowptr, const int32_t* row,
+                            const int32_t* col, int64_t E, const int32_t* node_ptr, int n_parts, float* w, void* ws,
+                            size_t ws_bytes, void* stream);
 size_t geobi_calc_weight_ws_bytes(void);
 int geobi_calc_weight(const float* pos, const float* normal, const int32_t* row, const int32_t* col, int64_t E,
                       int64_t extra_zero_edges, float* w, float* mean_len, void* ws, size_t ws_bytes, void* stream);
