@@ -1053,7 +1053,9 @@ static hipError_t lookback_scan(const int* in, int* out, int64_t n, hipStream_t 
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, 4096 * sizeof(unsigned long long) + 256);
     if (e != hipSuccess) return e;
-    e = hipMemset(p, 0, 4096 * sizeof(unsigned long long) + 256);
+    // zeroed ON THE LAUNCH STREAM: a null-stream memset is not ordered against a non-blocking stream, and a host thread
+    // that starts later (one context per thread) initialises its state while other threads' kernels are in flight
+    e = hipMemsetAsync(p, 0, 4096 * sizeof(unsigned long long) + 256, s);
     if (e != hipSuccess) return e;
     g_scan_state = (unsigned long long*)p;
     g_scan_ticket = (int*)((char*)p + 4096 * sizeof(unsigned long long));

@@ -28,7 +28,8 @@ _GROW_STREAMS = {}
 
 def _grow_stream(dev):
     """One side stream per device for the growth chain: it runs beside the patches' own work on the caller's stream."""
-    key = (dev.type, dev.index)
+    import threading
+    key = (dev.type, dev.index, threading.get_ident())           # one chain per host thread (predict_many)
     if key not in _GROW_STREAMS:
         _GROW_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _GROW_STREAMS[key]
@@ -297,3 +298,47 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
         out['angle2'] = float(network.error_n(computer_face_normal(Vu, fv), Nt))
     ph.tick('merge+update')
     return out
+
+
+def predict_many(net, meshes, workers=2, **kwargs):
+    """test_dual.py:90-148 (predict_dir) over a list of meshes, `workers` of them in flight together: every worker is a
+    host thread with its own stream, i.e. its own context of the library (arena, side streams, growth chain, mailbox are
+    per host thread / per stream), so one mesh's host waits -- size reads, patch sizes -- sit under another mesh's kernels.
+    meshes: list of (points, faces) or (points, faces, gt_points); kwargs as predict_mesh.  -> list of its results, in order."""
+    import threading
+    dev = next(net.parameters()).device
+    results, errors = [None] * len(meshes), []
+    nxt = [0]
+    lock = threading.Lock()
+    main = torch.cuda.current_stream(dev)
+
+    def run():
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(main)
+        try:
+            with torch.cuda.stream(stream):
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(meshes):
+                        break
+                    m = meshes[i]
+                    kw = dict(kwargs)
+                    if len(m) > 2 and m[2] is not None:
+                        kw['gt_points'] = m[2]
+                    results[i] = predict_mesh(net, m[0], m[1], **kw)
+            stream.synchronize()
+        except Exception as e:                                    # noqa: BLE001
+            errors.append(e)
+    if workers <= 1:
+        run()
+    else:
+        threads = [threading.Thread(target=run) for _ in range(min(int(workers), max(1, len(meshes))))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    if errors:
+        raise errors[0]
+    return results

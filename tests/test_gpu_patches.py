@@ -379,3 +379,25 @@ def test_executor_on_open_patches_equals_module_path(dev):
     assert torch.equal(one['Np'], ref['Np']) and torch.equal(one['Vp'], ref['Vp'])
     assert executor.STATS['calls'] - before['calls'] >= 3 + out['n_patches']
     assert executor.STATS['fallback'] == before['fallback']
+
+
+def test_meshes_in_flight_together_equal_one_by_one(dev):
+    """patches.predict_many: two and three host threads, each with its own stream (= its own context of the library),
+    run whole-mesh inference incl. the patch split at the same time; every mesh gets the bits it gets on its own.
+    (Round 4 found the look-back scan's state zeroed on the null stream, which a thread starting later raced with.)"""
+    from geobi_gnn_amd import meshgen, network, patches
+    torch.manual_seed(1)
+    net = network.DualGNN().to(dev).eval()
+    meshes = []
+    for i, n in enumerate((10, 16, 22, 14, 22, 12)):
+        noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed=60 + i)
+        meshes.append((torch.as_tensor(noisy, dtype=torch.float32, device=dev),
+                       torch.as_tensor(faces, dtype=torch.int32, device=dev), None))
+    want = [patches.predict_mesh(net, p, f, sub_size=3000, n_iter=5) for p, f, _ in meshes]
+    assert max(w['n_patches'] for w in want) >= 3
+    for workers in (2, 3):
+        for _ in range(3):
+            got = patches.predict_many(net, meshes, workers=workers, sub_size=3000, n_iter=5)
+            for g, w in zip(got, want):
+                assert g['n_patches'] == w['n_patches']
+                assert torch.equal(g['Np'], w['Np']) and torch.equal(g['V_updated'], w['V_updated'])
