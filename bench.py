@@ -465,8 +465,8 @@ def log(msg):
     print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
-PMC_SUMMARY = 'profiles/r03_pmc_feast_fused.json'
-PMC_MFMA = 'profiles/r03_pmc_mfma.json'
+PMC_SUMMARY = 'profiles/r04_pmc_feast_fused.json'
+PMC_MFMA = 'profiles/r04_pmc_mfma.json'
 
 
 def pmc_traffic(kernel):

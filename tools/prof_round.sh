@@ -2,7 +2,7 @@
 # bench line, per-kernel rocprofv3 stats of the same command, PMC passes (FETCH_SIZE / WRITE_SIZE separately),
 # inference configs, the training-driver run and the test-list evaluation.  Outputs under gpurun_out/<tag>_*.
 set -e
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 echo "bench done"
@@ -20,6 +20,8 @@ python bench.py --freq 16 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 
 GEOBI_TILE16=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra > gpurun_out/${TAG}_bench_tile32.json 2>/dev/null
 GEOBI_NET_EXECUTOR=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > gpurun_out/${TAG}_bench_module_path.json 2>/dev/null
 GEOBI_NET_EXECUTOR=0 GEOBI_FUSED=0 GEOBI_CHAIN_POOL=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > gpurun_out/${TAG}_bench_round1_path.json 2>/dev/null
+python bench.py --groups 2 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra > gpurun_out/${TAG}_bench_groups2.json 2>/dev/null
+python tools/patch_phases.py 87 20000 > gpurun_out/${TAG}_patch_phases.txt 2>&1
 echo "inference + A/B lines done"
 python tools/train_synthetic.py --max_epoch 40 --freq 32 --n_train 24 --n_eval 6 --lr 0.002 --lr_sch step --lr_step 12 --lr_decay 0.5 --batch_size 4 --out gpurun_out/${TAG}_net_freq32.pt > gpurun_out/${TAG}_train_synthetic_freq32.jsonl 2> gpurun_out/${TAG}_train.err
 python tools/test_synthetic.py --model gpurun_out/${TAG}_net_freq32.pt --sub_size 20000 --json gpurun_out/${TAG}_test_synthetic.json > gpurun_out/${TAG}_test_synthetic.log 2>&1
