@@ -297,6 +297,7 @@ int update_position2(const float* points, const int32_t* fv, const int32_t* vf, 
 size_t head_bwd_ws_bytes(int64_t N, int Cin, int K);
 // head_fused.hip
 bool head_fused_supported(int Cin, int K, int nout);
+int set_head_precision(int mode);
 int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
                    int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid, float* raw,
                    float* out, hipStream_t s);

@@ -11,6 +11,8 @@
 //   "accumulator" k(r, half) = row(r, half)     -- a C/D tile is fed back as the B operand as is
 #include "common.h"
 
+#include <cstdlib>
+
 namespace geobi {
 
 namespace {
@@ -107,6 +109,163 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(
   }
   __syncthreads();
   // thread t < 32 finishes node n0 + t: the four waves' shares in wave order, bias, finish
+  if (threadIdx.x < 32) {
+    const int node = n0 + threadIdx.x;
+    if (node >= N) return;
+    float v[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      v[o] = ((s_part[0][threadIdx.x][o] + s_part[1][threadIdx.x][o]) + s_part[2][threadIdx.x][o]) +
+             s_part[3][threadIdx.x][o] + b2[o];
+      raw[(size_t)node * NOUT + o] = v[o];
+    }
+    float res[3];
+    if (mode == 0) {
+#pragma unroll
+      for (int cidx = 0; cidx < 3; ++cidx) {
+        float t = (NOUT == 3) ? v[cidx % NOUT] : v[0] * dd[(size_t)node * 3 + cidx];
+        res[cidx] = t + resid[(size_t)node * ld_resid + cidx];
+      }
+    } else {
+      float len = fmaxf(sqrtf(v[0] * v[0] + v[1 % NOUT] * v[1 % NOUT] + v[2 % NOUT] * v[2 % NOUT]), kEps);
+#pragma unroll
+      for (int cidx = 0; cidx < 3; ++cidx) res[cidx] = v[cidx % NOUT] / len;
+    }
+    out[(size_t)node * 3] = res[0]; out[(size_t)node * 3 + 1] = res[1]; out[(size_t)node * 3 + 2] = res[2];
+  }
+}
+
+// ------------------------------------------------------------------------------ forward, split precision
+// The first GEMM (x W1^T: the head's 2 N 32 1024 flops) as SIX bf16 products with fp32 accumulation: every fp32 operand is
+// cut into three bf16 pieces a = a1 + a2 + a3 (each the round-to-nearest bf16 of what is left: 3 x 8 = 24 significand bits),
+// and a b = a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2 (+ terms below 2^-32 |a b|), every partial product exact in the
+// fp32 accumulator.  On the path's real operands this form is 0.5-0.9 x plain fp32's own distance to fp64
+// (tools/bf16_split_study.py, profiles/r04_bf16_split_study.txt).  v_mfma_f32_32x32x16_bf16 runs at 16 x the fp32 MFMA rate
+// (32 cycles for K = 16 against 64 for K = 2): a 32-unit chunk is 12 instructions = 384 matrix cycles instead of 16 = 1 024,
+// and -- unlike the fp32 shapes -- it leaves the SIMD's vector issue slots to the other waves' VALU work.
+// Behind geobi_set_head_precision(1) / GEOBI_HEAD_BF16X3=1; the default path stays exact fp32.
+// Operand maps (cdna_hip_programming: lane l, r = l & 31, h = l >> 5): A[row r][k = 8 h + j], B[k = 8 h + j][col r], j = 0..7
+// per K = 16 block; C/D as the fp32 shape (column on the lane, acc_row(reg, h)), so the epilogue is the fp32 kernel's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 { bf16x8 p[3]; };
+
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+  Split3 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = (__bf16)v[j];
+    const float r1 = v[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    o.p[0][j] = a; o.p[1][j] = b; o.p[2][j] = (__bf16)r2;
+  }
+  return o;
+}
+
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[8]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  const float4 a = q[0], b = q[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// acc += a b over one K = 16 block, smallest terms first
+__device__ __forceinline__ f32x16 mfma6(const Split3& a, const Split3& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// W1 [HID, CIN] fp32 -> its three bf16 pieces, [3][HID][CIN] (once per call: 32 K elements)
+__global__ void head_split_w1_kernel(const float* __restrict__ w1, __bf16* __restrict__ pk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HID * CIN) return;
+  const float v = w1[i];
+  const __bf16 a = (__bf16)v;
+  const float r1 = v - (float)a;
+  const __bf16 b = (__bf16)r1;
+  pk[i] = a; pk[HID * CIN + i] = b; pk[2 * HID * CIN + i] = (__bf16)(r1 - (float)b);
+}
+
+__device__ __forceinline__ Split3 load_split(const __bf16* __restrict__ pk, size_t off) {
+  Split3 o;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) o.p[p] = *reinterpret_cast<const bf16x8*>(pk + (size_t)p * HID * CIN + off);
+  return o;
+}
+
+template <int NOUT>
+__global__ __launch_bounds__(256) void head_fwd_fused_bf16x3_kernel(
+    const float* __restrict__ x, int N, const __bf16* __restrict__ w1p, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float slope, int mode,
+    const float* __restrict__ dd, const float* __restrict__ resid, int ld_resid, float* __restrict__ raw,
+    float* __restrict__ out) {
+  __shared__ float s_part[4][32][NOUT + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * 32;
+  const int row = min(n0 + l31, N - 1);
+  // the lane's share of its node row: k = 8 half + j of both K = 16 blocks, in three bf16 pieces
+  Split3 ax[2];
+  {
+    float v[8];
+    load8(x + (size_t)row * CIN + 8 * half, v);      ax[0] = split3(v);
+    load8(x + (size_t)row * CIN + 16 + 8 * half, v); ax[1] = split3(v);
+  }
+  float part[16][NOUT];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) part[r][o] = 0.f;
+
+  auto chunk = [&](int c, const Split3& bw0, const Split3& bw1) {
+    const int j = c * 32 + l31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma6(ax[0], bw0, acc);
+    acc = mfma6(ax[1], bw1, acc);
+    const float b1v = b1[j];
+    float w2v[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) w2v[o] = w2[(size_t)o * HID + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float h = acc[r] + b1v;
+      h = h > 0.f ? h : h * slope;
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) part[r][o] = fmaf(h, w2v[o], part[r][o]);
+    }
+  };
+  // wave w owns chunks w, w + 4, ...; the next chunk's W1 pieces are in flight while the current chunk multiplies
+  const size_t wl = (size_t)l31 * CIN + 8 * half;
+  Split3 wa0 = load_split(w1p, wl + (size_t)wave * 32 * CIN), wa1 = load_split(w1p, wl + (size_t)wave * 32 * CIN + 16);
+  for (int c = wave; c < NCHUNK; c += 8) {
+    const Split3 wb0 = load_split(w1p, wl + (size_t)(c + 4) * 32 * CIN), wb1 = load_split(w1p, wl + (size_t)(c + 4) * 32 * CIN + 16);
+    chunk(c, wa0, wa1);
+    if (c + 8 < NCHUNK) { wa0 = load_split(w1p, wl + (size_t)(c + 8) * 32 * CIN); wa1 = load_split(w1p, wl + (size_t)(c + 8) * 32 * CIN + 16); }
+    chunk(c + 4, wb0, wb1);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float v = part[r][o];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      part[r][o] = v;
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (l31 != r) continue;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) s_part[wave][acc_row(r, half)][o] = part[r][o];
+  }
+  __syncthreads();
   if (threadIdx.x < 32) {
     const int node = n0 + threadIdx.x;
     if (node >= N) return;
@@ -386,10 +545,33 @@ extern "C" int geobi_debug_head_stamps(void* host_dst, size_t bytes) {
 
 bool head_fused_supported(int Cin, int K, int nout) { return Cin == CIN && K == HID && (nout == 1 || nout == 3); }
 
+// 0: exact fp32 MFMA (default); 1: the first GEMM of the heads as six bf16 products (head_fwd_fused_bf16x3_kernel)
+static std::atomic<int> g_head_precision{[] { const char* e = getenv("GEOBI_HEAD_BF16X3"); return (e && atoi(e) != 0) ? 1 : 0; }()};
+int set_head_precision(int mode) {
+  GEOBI_REQUIRE(mode == 0 || mode == 1, "head precision: 0 (fp32) or 1 (3 x bf16 split, six products)");
+  g_head_precision = mode;
+  return 0;
+}
+
 int head_fwd_fused(const float* x, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2,
                    int nout, float slope, int mode, const float* dd, const float* resid, int ld_resid, float* raw,
                    float* out, hipStream_t s) {
   int blocks = cdiv(N, 32);
+  if (g_head_precision.load(std::memory_order_relaxed) == 1) {
+    // the pieces of W1 (192 KB) live in a per-context buffer the library owns (the one allocation of this mode); they are
+    // re-formed on every call, on the call's stream: the weights move with every optimiser step
+    static thread_local __bf16* pack = nullptr;
+    if (pack == nullptr) GEOBI_HIP(hipMalloc((void**)&pack, (size_t)3 * HID * CIN * sizeof(__bf16)));
+    head_split_w1_kernel<<<cdiv(HID * CIN, 256), 256, 0, s>>>(w1, pack);
+    if (nout == 3)
+      head_fwd_fused_bf16x3_kernel<3><<<blocks, 256, 0, s>>>(x, (int)N, pack, b1, w2, b2, slope, mode, dd, resid, ld_resid,
+                                                             raw, out);
+    else
+      head_fwd_fused_bf16x3_kernel<1><<<blocks, 256, 0, s>>>(x, (int)N, pack, b1, w2, b2, slope, mode, dd, resid, ld_resid,
+                                                             raw, out);
+    GEOBI_LAUNCH_OK();
+    return 0;
+  }
   if (nout == 3)
     head_fwd_fused_kernel<3><<<blocks, 256, 0, s>>>(x, (int)N, w1, b1, w2, b2, slope, mode, dd, resid, ld_resid, raw,
                                                     out);

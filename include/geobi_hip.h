@@ -241,6 +241,13 @@ int geobi_face_geom_bwd(const float* verts, const int32_t* fv, const float* gout
 int geobi_head_fwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    const float* b2, int nout, float slope, int mode, const float* dd, const float* resid,
                    int ld_resid, float* h, float* raw, float* out, void* stream);
+/* Precision of the heads' 32 -> 1024 product (process-wide switch, default 0; GEOBI_HEAD_BF16X3=1 starts with 1):
+ *   0  exact fp32 on v_mfma_f32_32x32x2_f32 -- what every number of the bench line and every parity test uses
+ *   1  the same product as SIX bf16 products with fp32 accumulation (each operand cut into three bf16 pieces: 24 significand
+ *      bits; v_mfma_f32_32x32x16_bf16, 16 x the fp32 matrix rate): not bit-identical to mode 0, but no farther from fp64 than
+ *      mode 0 is on the path's operands (profiles/r04_bf16_split_study.txt, test_head_split_precision_*).  A labelled variant:
+ *      the reference computes in fp32 (code/network.py:324-343).                                                          */
+int geobi_set_head_precision(int mode);
 size_t geobi_head_bwd_ws_bytes(int64_t N, int Cin, int K);
 int geobi_head_bwd(const float* x, int Cin, int64_t N, const float* w1, const float* b1, int K, const float* w2,
                    int nout, float slope, int mode, const float* dd, const float* h, const float* raw, const float* gout,

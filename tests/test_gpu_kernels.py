@@ -635,3 +635,36 @@ def test_softmax_exp_against_fp64(dev):
     assert float((got[~normal] - want[~normal]).abs().max()) <= tiny
     assert float(got[~normal].min()) >= 0.0 and bool(torch.isfinite(got).all())
     assert float(got[x.cpu() == 0].min()) == 1.0
+
+
+def test_head_split_precision_forward(dev):
+    """geobi_set_head_precision(1): the heads' 32 -> 1024 product as six bf16 products with fp32 accumulation.  Not
+    bit-identical to the fp32 form, but no farther from fp64: the bar is 2 x the fp32 kernel's own distance (measured
+    0.9 x), for both heads (3 outputs + normalisation; 1 output along depth_direction + residual)."""
+    from geobi_gnn_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(4)
+    N = 5000
+    x = torch.randn(N, 32, device=dev) * 3
+    w1 = (torch.rand(1024, 32, device=dev) * 2 - 1) / 32 ** 0.5
+    b1 = (torch.rand(1024, device=dev) * 2 - 1) / 32 ** 0.5
+    resid = torch.randn(N, 6, device=dev)
+    ddir = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1)
+    try:
+        for nout, mode in ((3, 1), (3, 0), (1, 0)):
+            w2 = (torch.rand(nout, 1024, device=dev) * 2 - 1) / 32
+            b2 = (torch.rand(nout, device=dev) * 2 - 1) / 32
+            pre = x.double() @ w1.double().t() + b1.double()
+            want = torch.nn.functional.leaky_relu(pre, 0.2) @ w2.double().t() + b2.double()
+            errs = []
+            for prec in (0, 1):
+                assert lib.geobi_set_head_precision(prec) == 0
+                raw = torch.empty(N, nout, device=dev); out = torch.empty(N, 3, device=dev)
+                L.call('geobi_head_fwd', L.ptr(x), 32, N, L.ptr(w1), L.ptr(b1), 1024, L.ptr(w2), L.ptr(b2), nout, 0.2, mode,
+                       L.ptr(ddir) if nout == 1 else None, None if mode == 1 else L.ptr(resid), 6, None, L.ptr(raw), L.ptr(out),
+                       L.stream())
+                errs.append(float((raw.double() - want).abs().max() / want.abs().max()))
+            assert errs[0] < 1e-5 and errs[1] <= 2.0 * errs[0] + 1e-8, errs
+        assert lib.geobi_set_head_precision(2) != 0
+    finally:
+        lib.geobi_set_head_precision(0)
