@@ -29,7 +29,7 @@ _GROW_STREAMS = {}
 def _grow_stream(dev):
     """One side stream per device for the growth chain: it runs beside the patches' own work on the caller's stream."""
     import threading
-    key = (dev.type, dev.index, threading.get_ident())           # one chain per host thread (predict_many)
+    key = (dev.type, dev.index, threading.get_ident())           # one chain per host thread (predict_many keeps its threads)
     if key not in _GROW_STREAMS:
         _GROW_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _GROW_STREAMS[key]
@@ -120,35 +120,37 @@ def split_faces(points, fv, submesh_size, incidence=None, vf32=None, ahead=None)
     gs.wait_stream(main)
     ahead = int(ahead or min(32, 2 * (F + sub - 1) // sub + 2))
     k = 0
-    while True:
-        box_ptr = ctypes.c_void_p(0)
-        L.call('geobi_host_mailbox', ahead, ctypes.byref(box_ptr))
-        box = (ctypes.c_int32 * ahead).from_address(box_ptr.value)
-        with torch.cuda.stream(gs):
-            slab = torch.empty(ahead * sub, dtype=torch.int32, device=dev)
-            events = []
+    try:
+        while True:
+            box_ptr = ctypes.c_void_p(0)
+            L.call('geobi_host_mailbox', ahead, ctypes.byref(box_ptr))
+            box = (ctypes.c_int32 * ahead).from_address(box_ptr.value)
+            with torch.cuda.stream(gs):
+                slab = torch.empty(ahead * sub, dtype=torch.int32, device=dev)
+                events = []
+                for i in range(ahead):
+                    L.call('geobi_patch_grow', L.ptr(fv), L.ptr(vf32), W, F, V, L.ptr(d2), -1, sub, 0, k + i + 1, L.ptr(state),
+                           slab.data_ptr() + 4 * i * sub, None, box_ptr.value + 4 * i, 1, gs.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(gs)
+                    events.append(ev)
+            slab.record_stream(main)
             for i in range(ahead):
-                L.call('geobi_patch_grow', L.ptr(fv), L.ptr(vf32), W, F, V, L.ptr(d2), -1, sub, 0, k + i + 1, L.ptr(state),
-                       slab.data_ptr() + 4 * i * sub, None, box_ptr.value + 4 * i, 1, gs.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(gs)
-                events.append(ev)
-        slab.record_stream(main)
-        for i in range(ahead):
-            spins = 0
-            while box[i] == 0:
-                spins += 1
-                if (spins & 0xfff) == 0 and gs.query() and box[i] == 0:
-                    raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % (k + i))
-            n = (box[i] - 1) // 2
-            if n == 0:
-                for j in range(i + 1, ahead):          # the rest of the round only reports "no patch": let it, the
-                    while box[j] == 0:                 # mailbox is handed out again by the next split
-                        pass
-                return
-            main.wait_event(events[i])
-            yield slab[i * sub:i * sub + n]
-        k += ahead
+                spins = 0
+                while box[i] == 0:
+                    spins += 1
+                    if (spins & 0xfff) == 0 and gs.query() and box[i] == 0:
+                        raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % (k + i))
+                n = (box[i] - 1) // 2
+                if n == 0:
+                    return
+                main.wait_event(events[i])
+                yield slab[i * sub:i * sub + n]
+            k += ahead
+    finally:
+        # whatever ends the walk (the last patch, an error, a consumer that stops early): nothing of the chain may still be
+        # running when its buffers and the mailbox go back
+        gs.synchronize()
 
 
 def split_patches(points, fv, submesh_size, incidence=None, keep=None, vf32=None):
@@ -300,45 +302,62 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     return out
 
 
+_POOLS = {}          # workers -> ThreadPoolExecutor: the worker threads (= library contexts: mailbox, scan state, side streams,
+_TLS = None          # growth stream) live as long as the process, so repeated calls allocate nothing new
+
+
 def predict_many(net, meshes, workers=2, **kwargs):
     """test_dual.py:90-148 (predict_dir) over a list of meshes, `workers` of them in flight together: every worker is a
     host thread with its own stream, i.e. its own context of the library (arena, side streams, growth chain, mailbox are
     per host thread / per stream), so one mesh's host waits -- size reads, patch sizes -- sit under another mesh's kernels.
-    meshes: list of (points, faces) or (points, faces, gt_points); kwargs as predict_mesh.  -> list of its results, in order."""
+    The threads are kept (one pool per worker count).  meshes: list of (points, faces) or (points, faces, gt_points);
+    kwargs as predict_mesh.  -> list of its results, in order."""
     import threading
+    from concurrent.futures import ThreadPoolExecutor
+    global _TLS
+    if _TLS is None:
+        _TLS = threading.local()
     dev = next(net.parameters()).device
-    results, errors = [None] * len(meshes), []
+    workers = max(1, min(int(workers), len(meshes)))
+    if workers == 1:
+        out = []
+        for m in meshes:
+            kw = dict(kwargs)
+            if len(m) > 2 and m[2] is not None:
+                kw['gt_points'] = m[2]
+            out.append(predict_mesh(net, m[0], m[1], **kw))
+        return out
+    pool = _POOLS.get(workers)
+    if pool is None:
+        pool = _POOLS[workers] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix='geobi-infer')
+    main = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    results = [None] * len(meshes)
     nxt = [0]
     lock = threading.Lock()
-    main = torch.cuda.current_stream(dev)
 
     def run():
-        stream = torch.cuda.Stream(device=dev)
-        stream.wait_stream(main)
-        try:
-            with torch.cuda.stream(stream):
-                while True:
-                    with lock:
-                        i = nxt[0]
-                        nxt[0] += 1
-                    if i >= len(meshes):
-                        break
-                    m = meshes[i]
-                    kw = dict(kwargs)
-                    if len(m) > 2 and m[2] is not None:
-                        kw['gt_points'] = m[2]
-                    results[i] = predict_mesh(net, m[0], m[1], **kw)
-            stream.synchronize()
-        except Exception as e:                                    # noqa: BLE001
-            errors.append(e)
-    if workers <= 1:
-        run()
-    else:
-        threads = [threading.Thread(target=run) for _ in range(min(int(workers), max(1, len(meshes))))]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-    if errors:
-        raise errors[0]
+        stream = getattr(_TLS, 'stream', None)
+        if stream is None or stream.device != dev:
+            stream = _TLS.stream = torch.cuda.Stream(device=dev)
+        stream.wait_event(ready)
+        with torch.cuda.stream(stream):
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= len(meshes):
+                    break
+                m = meshes[i]
+                kw = dict(kwargs)
+                if len(m) > 2 and m[2] is not None:
+                    kw['gt_points'] = m[2]
+                results[i] = predict_mesh(net, m[0], m[1], **kw)
+        stream.synchronize()
+    futures = [pool.submit(run) for _ in range(workers)]
+    errors = [f.exception() for f in futures]
+    for e in errors:
+        if e is not None:
+            raise e
     return results
