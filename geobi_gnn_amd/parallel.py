@@ -138,7 +138,9 @@ class GradBucket(object):
             return self.flat
         world = dist.get_world_size()
         tail, head = self.flat[offset:], self.flat[:offset]
-        if events and self.flat.is_cuda and comm_stream is not None:
+        # the early collective needs a backend that reduces on the device (RCCL); gloo stages through the host and only
+        # makes sense one collective after the other (the rehearsal / CPU path)
+        if events and self.flat.is_cuda and comm_stream is not None and dist.get_backend() == 'nccl':
             for ev in events:
                 comm_stream.wait_event(ev)
             with torch.cuda.stream(comm_stream):
