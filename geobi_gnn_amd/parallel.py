@@ -129,12 +129,14 @@ class GradBucket(object):
             off += p.numel()
         raise ValueError('the bucket does not hold the network\'s parameters')
 
-    def all_reduce_mean_split(self, offset, events=None, comm_stream=None):
+    def all_reduce_mean_split(self, offset, events=None, comm_stream=None, _single_rank_too=False):
         """The same reduction as `all_reduce_mean` in two collectives: the tail [offset:] (the facet half) FIRST -- on
         `comm_stream` behind `events` (torch.cuda.Event list recorded by geobi_net_backward_facet_events) when given, so
         that it runs under the vertex branch's backward -- then the head [:offset].  Element-wise the same sums, so the
         reduced bucket is identical to the one-shot all-reduce."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_available() and dist.is_initialized()):
+            return self.flat
+        if dist.get_world_size() == 1 and not _single_rank_too:      # (tests run the collectives on one rank as well)
             return self.flat
         world = dist.get_world_size()
         tail, head = self.flat[offset:], self.flat[:offset]

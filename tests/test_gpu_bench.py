@@ -61,3 +61,49 @@ def test_bench_two_ranks_from_a_bare_shell():
     assert cfg['world_size'] == 2 and cfg['collective_us'] > 0
     assert 0 < cfg['rank_ms_per_step']['min'] <= cfg['rank_ms_per_step']['max']
     assert cfg['rank_ms_per_step']['max'] <= out['ms_per_step'] * 1.001
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from geobi_gnn_amd import network
+from geobi_gnn_amd.parallel import FlatParameters
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == 'nccl'
+net = network.DualGNN().to(dev)
+bucket = FlatParameters(net).bucket
+g = torch.Generator().manual_seed(5)
+mine = torch.randn(bucket.flat.numel(), generator=g).to(dev)
+bucket.flat.copy_(mine)
+dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)               # what all_reduce_mean issues at N > 1
+torch.cuda.synchronize()
+assert torch.equal(bucket.flat, mine)
+off = bucket.facet_offset(net)
+evs = [torch.cuda.Event(), torch.cuda.Event()]
+for e in evs:
+    e.record()
+comm = torch.cuda.Stream(device=dev)
+out = bucket.all_reduce_mean_split(off, evs, comm, _single_rank_too=True)     # early collective on the comm stream
+torch.cuda.synchronize()
+assert torch.equal(out, mine)
+dist.barrier()
+dist.destroy_process_group()
+print('rccl ok')
+'''
+
+
+def test_rccl_single_rank_runs_the_collectives(tmp_path):
+    """RCCL itself only runs in the driver's multi-GPU tier; on the one-GPU box the nccl backend is at least brought up on
+    a single rank and runs the collectives the data-parallel step issues -- the one-shot all-reduce of the flat bucket and
+    the split form with its early collective on a communication stream behind two events."""
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(_RCCL_WORKER % {'root': ROOT})
+    from helpers import free_port
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'rccl ok' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
