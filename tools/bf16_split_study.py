@@ -136,10 +136,7 @@ def main():
     p = x @ u.t()
     logit_e = p[col] - p[row] + c                             # u(x_j - x_i) + c per edge
     logit_s = c.expand(N, 9)                                  # self loop
-    m = torch.maximum(torch.zeros(N, 9, dtype=torch.float64).index_reduce_(0, row, logit_e, 'amax', include_self=False), logit_s)
-    qe, qs = (logit_e - m[row]).exp(), (logit_s - m).exp()
-    den_e = torch.zeros(N, 9, dtype=torch.float64)
-    # softmax is over the 9 heads of ONE edge, not over edges: redo properly
+    # the softmax runs over the 9 heads of ONE edge (FeaStConv), not over a node's edges
     qe = torch.softmax(logit_e, dim=1)
     qs = torch.softmax(logit_s, dim=1)
     z = torch.zeros(N, 9, C, dtype=torch.float64)
