@@ -505,6 +505,18 @@ int geobi_patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F
                     pick_next, S(stream));
 }
 
+// Spin (without the caller's interpreter lock: ctypes releases it for the call) until a mailbox word is non-zero or `stream`
+// has drained without writing it; returns the word (0: the stream ran dry).
+int geobi_host_mailbox_wait(const int32_t* word, void* stream) {
+  if (word == nullptr) return 0;
+  long spins = 0;
+  int v;
+  while ((v = __atomic_load_n(word, __ATOMIC_ACQUIRE)) == 0) {
+    if ((++spins & 0x3fff) == 0 && hipStreamQuery(S(stream)) != hipErrorNotReady) return __atomic_load_n(word, __ATOMIC_ACQUIRE);
+  }
+  return v;
+}
+
 // Mapped host memory a kernel can hand small results over through (patch sizes): `n` int32 slots, zeroed, valid until the
 // next call from the same host thread asks for more.
 int geobi_host_mailbox(int n, int32_t** host_ptr) {

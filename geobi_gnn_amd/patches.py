@@ -136,12 +136,11 @@ def split_faces(points, fv, submesh_size, incidence=None, vf32=None, ahead=None)
                     events.append(ev)
             slab.record_stream(main)
             for i in range(ahead):
-                spins = 0
-                while box[i] == 0:
-                    spins += 1
-                    if (spins & 0xfff) == 0 and gs.query() and box[i] == 0:
-                        raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % (k + i))
-                n = (box[i] - 1) // 2
+                # the wait runs inside the library (no interpreter lock held: other host threads keep working)
+                word = L.lib().geobi_host_mailbox_wait(ctypes.c_void_p(box_ptr.value + 4 * i), ctypes.c_void_p(gs.cuda_stream))
+                if word == 0:
+                    raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % (k + i))
+                n = (word - 1) // 2
                 if n == 0:
                     return
                 main.wait_event(events[i])

@@ -361,6 +361,8 @@ int geobi_patch_grow(const int32_t* fv, const int32_t* vf, int maxval, int64_t F
 /* n zeroed int32 slots of mapped HOST memory that a kernel can write (the patch sizes above); per host thread, valid until
  * that thread asks for more slots */
 int geobi_host_mailbox(int n, int32_t** host_ptr);
+/* waits (spinning) until *word != 0 and returns it; 0 when `stream` -- the one the writing kernel runs on -- drained first */
+int geobi_host_mailbox_wait(const int32_t* word, void* stream);
 size_t geobi_submesh_ws_bytes(int64_t n_sel, int64_t V);
 int geobi_submesh(const int32_t* fv, const int32_t* sel, int64_t n_sel, int64_t V, int32_t* v_idx, int32_t* f_sub,
                   int32_t* count, void* ws, size_t ws_bytes, void* stream);
