@@ -90,6 +90,26 @@ def test_groups_equal_the_union_step(dev, split):
         assert torch.equal(normals, npred[ptr_f[ix[0]]:ptr_f[ix[-1] + 1]])
 
 
+def test_groups_with_mean_pooling(dev):
+    """pool_type='mean' (net_util.py:131-134) through the grouped step: same bars as the max-pooling network."""
+    from geobi_gnn_amd import executor, network, meshgen
+    from geobi_gnn_amd.parallel import FlatParameters
+    torch.manual_seed(9)
+    net = network.DualGNN(pool_type='mean').to(dev)
+    bucket = FlatParameters(net).bucket
+    pairs = [meshgen.synthetic_dual_data(10 + 2 * (i % 2), 0.2, seed=80 + i) for i in range(4)]
+    dv, df = _union(pairs, [0, 1, 2, 3], dev)
+    vp, npred, lv, ln, g_ref = _union_step(net, bucket, dv, df)
+    tg = executor.TrainGroups(net, bucket).set_groups([_union(pairs, [0, 1], dev), _union(pairs, [2, 3], dev)])
+    losses = tg.step(); torch.cuda.synchronize()
+    assert tg.sequential_steps == 0
+    tot = losses.sum(0).tolist()
+    assert abs(tot[0] - lv) < 2e-6 * abs(lv) and abs(tot[1] - ln) < 2e-6 * abs(ln)
+    assert float((bucket.flat - g_ref).abs().max() / g_ref.abs().max()) < 1e-5
+    verts, normals = tg.prediction(0)
+    assert torch.equal(verts, vp[:verts.shape[0]]) and torch.equal(normals, npred[:normals.shape[0]])
+
+
 def test_group_order_does_not_change_a_bit(dev):
     from geobi_gnn_amd import executor
     net, bucket, pairs = _setup(dev)
