@@ -275,6 +275,7 @@ int geobi_set_match_round_cap(int cap) { set_match_round_cap(cap); return 0; }
 int geobi_set_tile_rows(int rows) { return set_tile_rows(rows); }
 int geobi_set_head_precision(int mode) { return set_head_precision(mode); }
 int geobi_set_rowpass_form(int staged, int chunked64) { return set_rowpass_form(staged, chunked64); }
+int geobi_set_column_parts(int parts) { return set_column_parts(parts); }
 
 size_t geobi_match_coarsen_ws_bytes(int64_t N) { return match_coarsen_ws_bytes(N); }
 int geobi_match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds, int init,

@@ -125,6 +125,7 @@ int feast_fused_dx(const float* g, int Cout, const float* p, const float* cvec, 
 bool feast_rowpass_fused_supported(int Cin, int Cb, int Cout);
 int set_tile_rows(int rows);
 int set_rowpass_form(int staged, int chunked64);
+int set_column_parts(int parts);
 int feast_rowpass_fused(const float* xa, const float* xb, int Ca, int Cin, const float* p, const float* cvec,
                         const int* rowptr, const int* col, int N, int LC, const float* ul, const float* gout,
                         const float* out_act, float slope, int Cout, const float* Wf, int Kp, float* g_out, float* dl,

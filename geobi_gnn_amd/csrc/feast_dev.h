@@ -64,6 +64,31 @@ __device__ __forceinline__ void load_hp(const float* __restrict__ row, float (&v
 __host__ __device__ __forceinline__ int xcd_grid(int blocks) { return (blocks + 7) / 8 * 8; }
 __device__ __forceinline__ int xcd_block(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
 
+// L2 warm-up of a read-only operand that EVERY workgroup of the launch streams (a layer's packed weights, 0.15-0.6 MB).
+// All tiles walk the same weight addresses at about the same time, so in a launch of one round or less nobody finds a line
+// in L2 that somebody else fetched earlier: each wave's 2-4 loads in flight then see the full fabric latency, and a tile's
+// matrix phase runs at a third of the matrix rate (stamps: tools/fused_stamps_small.py).  Here the first <= 32 workgroups
+// of every XCD request the whole operand up front -- one dword per 128-B line and lane, 64 lines per wave instruction, two
+// instructions per wave -- while their gather phase runs.  The loads go to LDS (global_load_lds_dword: no destination
+// register, nothing waits for the value; an inline-assembly load into a register was tried first and is unsafe -- the
+// compiler spills or copies a register it believes defined while the load is still in flight); their landing zone is 256 B
+// per wave that nothing reads.
+typedef __attribute__((address_space(3))) void* warm_lds_ptr;
+template <int NWAVES>
+__device__ __forceinline__ void warm_l2(const float* __restrict__ base, int bytes, bool on, float* scratch) {
+  const int nw = min((int)(gridDim.x >> 3), 32);
+  const int bi = blockIdx.x >> 3;
+  if (on && bi < nw) {
+    const int lines = bytes >> 7;
+    const int stride = nw * NWAVES * 64;
+    const int line = bi * (NWAVES * 64) + threadIdx.x;
+    float* dst = scratch + (threadIdx.x >> 6) * 64;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds(base + (size_t)min(line + r * stride, lines - 1) * 32, (warm_lds_ptr)dst, 4, 0, 0);
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* __restrict__ ptr, float (&v)[VEC]) {
   if constexpr (VEC == 4) {

@@ -100,7 +100,7 @@ struct Shape {
 template <int C, int MODE, int LC, int ROWS>
 constexpr int fused_lds_floats() {
   return Shape<C, MODE, ROWS>::TILE_FLOATS + Shape<C, MODE, ROWS>::SLOT_FLOATS + (LC > 0 ? LC * HP : 0) +
-         Shape<C, MODE, ROWS>::DP_FLOATS;
+         Shape<C, MODE, ROWS>::DP_FLOATS + 64 * Shape<C, MODE, ROWS>::NWV;      // + the landing zone of warm_l2
 }
 // K of the PACKED weights (both geometries read the same pack): the r' / z row rounded up to 16
 constexpr int fused_k(int C, int MODE) { return ((MODE == 0 ? H * C : H * C + 2 * HP) + KPAD - 1) / KPAD * KPAD; }
@@ -118,7 +118,12 @@ __device__ unsigned long long g_stamps[16384][8];
 
 // (Five waves per SIMD for the 32-channel instantiations -- 96 registers, LDS allows seven workgroups -- measured
 // 56.9 against 57.3 us for the dx kernel of the 64 -> 32 layers and slower elsewhere: not occupancy-bound.)
-template <int C, int MODE, int LC, int NT, int ROWS>
+// CS = 2 (16-row tiles only): the launch's grid has a second dimension and workgroup (tile, part) produces, of every
+// wave's 32-column group, the 16 columns [16 part, 16 part + 16) -- each wave runs ONE accumulator chain over the same
+// k range in the same order as the unsplit kernel (bit-identical columns), with half the matrix work and half the
+// weight traffic per workgroup; the gather phase is done by both parts.  For launches with fewer tiles than the chip has
+// workgroup slots (the coarse graph levels): see column_parts().
+template <int C, int MODE, int LC, int NT, int ROWS, int CS = 1>
 __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, int Ca, const float* __restrict__ p,
     const float* __restrict__ cvec, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -126,11 +131,13 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
     const float* __restrict__ dpd, const float* __restrict__ dl, const int* __restrict__ pos,
     const float* __restrict__ dpn, const float* __restrict__ Bp, int NOUT, const float* __restrict__ bias,
     float slope, float* __restrict__ out, int ldo, float* __restrict__ out1, int split, int ldo1,
-    float* __restrict__ tile_out) {
+    float* __restrict__ tile_out, int warm_on) {
   using S = Shape<C, MODE, ROWS>;
   constexpr int VEC = S::VEC, NP = S::NP, PV = S::PV, LD = S::LD, HC = S::HC, NCHUNK = S::NCHUNK;
   constexpr int TN = ROWS, NW = S::NWV, NTHREADS = 64 * NW;       // shadow the 32-row constants
   static_assert(NW % NT == 0, "column tiles divide the waves");
+  static_assert(CS == 1 || (CS == 2 && ROWS == 16), "column parts: two halves of the 16-row geometry's column groups");
+  const int cpart = CS > 1 ? blockIdx.y : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_slots = smem + S::TILE_FLOATS;
   float* s_u = s_slots + S::SLOT_FLOATS;
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
   if (tile * TN >= N) return;          // whole workgroup: surplus tile of the XCD-padded grid
 
   GEOBI_STAMP(0);
+  warm_l2<NW>(Bp, fused_k(C, MODE) * 32 * NT * (int)sizeof(float), warm_on, s_dp + S::DP_FLOATS);
   // ------------------------------------------------------------------ phase A: aggregate into registers
   const int g = lane / G, k = lane % G;
   const int nl = wave * NPW + g;                 // node within the tile
@@ -347,14 +355,23 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
         for (int i = S::KR_LAST + k; i < S::KC_LAST; i += G) zrow[i] = 0.f;          // K padding behind them
       }
     }
-    // ---- tile chunk x packed weights on the matrix cores.  The weights of a wave's k-range come from L2 in
-    // batches of BATCH k-blocks (one 16-B load per lane and block = 4 MFMAs per tile): the first batch is requested
-    // BEFORE the barrier that publishes the tile, every further one a whole batch ahead of its use, so the matrix pipe
-    // never waits on L2 latency; the A operand is read from LDS one block ahead.
+    // ---- tile chunk x packed weights on the matrix cores.  The weights of a wave's k-range come from L2, one 16-B load
+    // per lane, k-block and column tile (= 4 MFMAs per tile), always requested BEFORE the barrier that publishes the tile
+    // and then ahead of their use in one of two ways that hold the same number of registers:
+    //   two batches  "current" and "next" sets of BATCH blocks, the next batch requested at the top of the current one:
+    //                a lead of BATCH blocks.  The short k-ranges (K split over the waves) and the launches with four waves
+    //                per SIMD run best on it (the level-0 layers: 58.3 against 61.5 us for the ring, same box).
+    //   ring         RING = 2 BATCH blocks in flight, a slot requested again right behind the MFMAs that read it: twice
+    //                the lead.  For the long k-ranges of the coarse levels (128 channels read, or one wave per column
+    //                group), where a launch has one or two waves per SIMD and nothing else hides the weight latency
+    //                (43.7 -> 37.1 us for the 128 -> 128 dx at 264 tiles; profiles/r04_weight_ring.txt).
+    // A is read from LDS one block ahead.
     {
       constexpr int KB = S::KB;
-      constexpr int BATCH = ROWS == 32 ? (VEC >= 8 ? 4 : 8) : (VEC >= 8 ? 2 : 4);
-      constexpr int WPB = ROWS == 32 ? 1 : 2;                      // weight loads per block (column tiles per wave)
+      constexpr int WPB = (ROWS == 32 || CS == 2) ? 1 : 2;         // weight loads per block (column tiles per wave)
+      constexpr int BATCH = (VEC >= 8 ? 4 : 8) / WPB;
+      constexpr bool USE_RING = VEC >= 8 || NT == 4;
+      constexpr int RING = 2 * BATCH;
       constexpr int BSTR = (KB / 4) * 32 * NT;                     // float4 per weight block
       const int nkb = ((c == NCHUNK - 1) ? S::KC_LAST : S::KC_FULL) / KB;
       const int kb_base = c * (S::KC_FULL / KB);
@@ -365,19 +382,37 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
       const float* arow = ROWS == 32 ? smem + l31 * LD + 4 * hf : smem + l15 * LD + 4 * kq;
       const float4* bcol = reinterpret_cast<const float4*>(Bp) + (size_t)kb_base * BSTR +
                            (ROWS == 32 ? (size_t)hf * (32 * NT) + ct * 32 + l31
-                                       : (size_t)kq * (32 * NT) + ct * 32 + l15);
-      float4 w_cur[BATCH][WPB], w_nxt[BATCH][WPB];
-      auto load_w = [&](float4 (&wv)[BATCH][WPB], int b) {
+                                       : (size_t)kq * (32 * NT) + ct * 32 + 16 * cpart + l15);
+      float4 w[RING][WPB];                                          // two batches: [0, BATCH) current, [BATCH, RING) next
+      auto load_w = [&](float4 (&wv)[WPB], int b) {                // clamped: always a valid address
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u)
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) wv[u][j] = bcol[(size_t)min(b + u, kb1 - 1) * BSTR + 16 * j];
+        for (int j = 0; j < WPB; ++j) wv[j] = bcol[(size_t)min(b, kb1 - 1) * BSTR + 16 * j];
       };
-      if (work) load_w(w_cur, kb0);
+      auto mma = [&](const float4& a, const float4 (&wv)[WPB]) {
+        if constexpr (ROWS == 32) {
+          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[0].x, macc, 0, 0, 0);
+          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[0].y, macc, 0, 0, 0);
+          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[0].z, macc, 0, 0, 0);
+          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[0].w, macc, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wv[0].x, acc0, 0, 0, 0);
+          if constexpr (WPB == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wv[WPB - 1].x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wv[0].y, acc0, 0, 0, 0);
+          if constexpr (WPB == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wv[WPB - 1].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wv[0].z, acc0, 0, 0, 0);
+          if constexpr (WPB == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wv[WPB - 1].z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wv[0].w, acc0, 0, 0, 0);
+          if constexpr (WPB == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wv[WPB - 1].w, acc1, 0, 0, 0);
+        }
+      };
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < (USE_RING ? RING : BATCH); ++u) load_w(w[u], kb0 + u);
+      }
       GEOBI_STAMP(3);
       __syncthreads();
       GEOBI_STAMP(4);
-      if (tile_out != nullptr) {
+      if (tile_out != nullptr && cpart == 0) {
         // the tile rows themselves (MODE 1: r' = [r | dp | dcs]) for the weight-gradient GEMM [x | 1]^T r'
         const int kc = (c == NCHUNK - 1) ? S::KR_LAST : S::KC_FULL;
         const int q4 = kc >> 2;                                    // float4 per row of this chunk
@@ -391,34 +426,35 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
       }
       if (work) {
         float4 a = *reinterpret_cast<const float4*>(arow + KB * kb0);
-        for (int b = kb0; b < kb1; b += BATCH) {
-          load_w(w_nxt, b + BATCH);                 // clamped: always a valid address
+        if constexpr (USE_RING) {
+          for (int b = kb0; b < kb1; b += RING) {
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) {
-            const float4 an = *reinterpret_cast<const float4*>(arow + KB * min(b + u + 1, kb1 - 1));
-            if (b + u < kb1) {
-              if constexpr (ROWS == 32) {
-                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w_cur[u][0].x, macc, 0, 0, 0);
-                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w_cur[u][0].y, macc, 0, 0, 0);
-                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w_cur[u][0].z, macc, 0, 0, 0);
-                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w_cur[u][0].w, macc, 0, 0, 0);
-              } else {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w_cur[u][0].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w_cur[u][WPB - 1].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w_cur[u][0].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w_cur[u][WPB - 1].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w_cur[u][0].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w_cur[u][WPB - 1].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w_cur[u][0].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w_cur[u][WPB - 1].w, acc1, 0, 0, 0);
-              }
+            for (int u = 0; u < RING; ++u) {
+              const float4 an = *reinterpret_cast<const float4*>(arow + KB * min(b + u + 1, kb1 - 1));
+              if (b + u < kb1) mma(a, w[u]);
+              // unconditional (clamped): behind a branch the compiler's vmcnt waits assume the load was skipped.  The
+              // scheduling barrier keeps the request HERE: left alone, the scheduler gathers an iteration's refills behind
+              // its last MFMA, which leaves the first blocks of the next iteration no lead at all
+              load_w(w[u], b + u + RING);
+              __builtin_amdgcn_sched_barrier(0);
+              a = an;
             }
-            a = an;
           }
+        } else {
+          for (int b = kb0; b < kb1; b += BATCH) {
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u)
+            for (int u = 0; u < BATCH; ++u) load_w(w[BATCH + u], b + BATCH + u);
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) w_cur[u][j] = w_nxt[u][j];
+            for (int u = 0; u < BATCH; ++u) {
+              const float4 an = *reinterpret_cast<const float4*>(arow + KB * min(b + u + 1, kb1 - 1));
+              if (b + u < kb1) mma(a, w[u]);
+              a = an;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) w[u][j] = w[BATCH + u][j];
+          }
         }
       }
     }
@@ -437,7 +473,7 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       red[wave][4 * kq + r][l15] = acc0[r];
-      red[wave][4 * kq + r][16 + l15] = acc1[r];
+      if constexpr (CS == 1) red[wave][4 * kq + r][16 + l15] = acc1[r];
     }
   }
   __syncthreads();
@@ -447,6 +483,7 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
   const int onode = tile * TN + row;
   GEOBI_STAMP(7);
   if (onode >= N) return;
+  if (CS == 2 && c2 >= 16) return;                 // a part holds 16 columns of every group
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float2 s = make_float2(0.f, 0.f);
@@ -455,7 +492,7 @@ __global__ __launch_bounds__(16 * ROWS, 4) void feast_fused_kernel(
       const float2 v = *reinterpret_cast<const float2*>(&red[q * NT + t][row][c2]);
       s.x += v.x; s.y += v.y;
     }
-    const int cidx = t * 32 + c2;
+    const int cidx = t * 32 + 16 * cpart + c2;
     if (cidx >= NOUT) continue;
     if constexpr (MODE == 0) {
       s.x += bias[cidx]; s.y += bias[cidx + 1];
@@ -1077,7 +1114,33 @@ bool tile16() {
   return g_tile_rows ? g_tile_rows == 16 : env_on;
 }
 
-template <int C, int MODE, int LC, int NT, int ROWS>
+// Column parts of a launch (feast_fused_kernel's CS): 2 when the layer reads 128 channels and the 16-row tiles alone would
+// fill less than half of the chip's workgroup slots -- level 2 of the bench batch, 264-424 tiles on 1 024 slots, where a
+// tile's matrix phase (one wave per SIMD, 0.3-0.6 MB of weights streamed per tile) is what the kernel's time follows:
+// 128 -> 128 dx 43.7 -> 33.0 us at 264 tiles, 65.2 -> 54.2 at 424.  Measured slower for 64-channel layers and from 768 tiles
+// up (profiles/r04_weight_ring.txt).  Same bits either way, so the choice may depend on N.
+std::atomic<int> g_col_parts{-1};          // -1: from the environment on first use; 0: per launch; 1 / 2: forced
+int g_col_parts_max_tiles = 512;
+int column_parts(int tiles) {
+  int v = g_col_parts.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* f = getenv("GEOBI_COLUMN_PARTS");
+    v = f ? atoi(f) : 0;
+    if (v < 0 || v > 2) v = 0;
+    if (const char* t = getenv("GEOBI_COLUMN_PARTS_MAX_TILES")) g_col_parts_max_tiles = atoi(t);
+    g_col_parts.store(v, std::memory_order_relaxed);
+  }
+  if (v != 0) return v;
+  return tiles <= g_col_parts_max_tiles ? 2 : 1;
+}
+
+// GEOBI_WARM_L2=0: without the up-front request of the packed weights (feast_dev.h: warm_l2) -- same-box A/B
+bool warm_l2_enabled() {
+  static const bool on = [] { const char* f = getenv("GEOBI_WARM_L2"); return !f || atoi(f) != 0; }();
+  return on;
+}
+
+template <int C, int MODE, int LC, int NT, int ROWS, int CS = 1>
 int launch_one(const float* xa, const float* xb, int Ca, const float* p, const float* cvec, const int* rowptr,
                const int* col, const int* deg_rowptr, int N, const float* xl, const float* ul, const float* dpd,
                const float* dl, const int* pos, const float* dpn, const float* Bp, int NOUT, const float* bias, float slope, float* out, int ldo, float* out1, int split,
@@ -1087,13 +1150,13 @@ int launch_one(const float* xa, const float* xb, int Ca, const float* p, const f
   static_assert(ROWS == 32 || lds <= 40960, "16-row tiles: four workgroups per CU");
   static std::atomic<bool> attr_set{false};   // several host threads may launch (one per mesh group)
   if (!attr_set) {
-    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT, ROWS>,
+    GEOBI_HIP(hipFuncSetAttribute((const void*)feast_fused_kernel<C, MODE, LC, NT, ROWS, CS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  feast_fused_kernel<C, MODE, LC, NT, ROWS><<<xcd_grid(cdiv(N, ROWS)), 16 * ROWS, lds, s>>>(
+  feast_fused_kernel<C, MODE, LC, NT, ROWS, CS><<<dim3(xcd_grid(cdiv(N, ROWS)), CS), 16 * ROWS, lds, s>>>(
       xa, xb, Ca, p, cvec, rowptr, col, deg_rowptr, N, xl, ul, dpd, dl, pos, dpn, Bp, NOUT, bias, slope, out, ldo, out1,
-      split, ldo1, tile_out);
+      split, ldo1, tile_out, warm_l2_enabled() ? 1 : 0);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -1110,6 +1173,14 @@ int launch_nt(int NT, const float* xa, const float* xb, int Ca, const float* p, 
   // dx with per-edge logits writes a 6- or 12-channel input gradient: one column tile
   constexpr bool kNarrowOnly = MODE == 1 && LC > 0;
   if (tile16()) {
+    // two column parts: 128 channels read, node-level logits (0.3-0.6 MB of weights per tile)
+    if constexpr (C >= 128 && LC == 0) {
+      if (column_parts(cdiv(N, 16)) == 2) {
+        if (NT == 1) return launch_one<C, MODE, LC, 1, 16, 2>(GEOBI_FUSED_ARGS);
+        if (NT == 2) return launch_one<C, MODE, LC, 2, 16, 2>(GEOBI_FUSED_ARGS);
+        if (NT == 4) return launch_one<C, MODE, LC, 4, 16, 2>(GEOBI_FUSED_ARGS);
+      }
+    }
     if (NT == 1) return launch_one<C, MODE, LC, 1, 16>(GEOBI_FUSED_ARGS);
     if constexpr (!kNarrowOnly) {
       if (NT == 2) return launch_one<C, MODE, LC, 2, 16>(GEOBI_FUSED_ARGS);
@@ -1198,6 +1269,14 @@ int launch_rowpass_fused128(const float* xa, const float* xb, int Ca, const floa
   return 0;
 }
 }  // namespace
+
+// column parts of the fused kernel from one process (parity tests, A/B timing): 1 / 2, 0 = chosen per launch
+int set_column_parts(int parts) {
+  if (parts < 0 || parts > 2) return set_error("fused kernel column parts: 1, 2 or 0 (per launch), got %d", parts);
+  column_parts(1);                           // the environment's tile limit is read once
+  g_col_parts.store(parts, std::memory_order_relaxed);
+  return 0;
+}
 
 // forms of the 64-channel backward row pass from one process (parity tests, A/B timing): 1 / 0, -1 = default
 int set_rowpass_form(int staged, int chunked64) {

@@ -139,6 +139,10 @@ int geobi_set_tile_rows(int rows);
  *   (32-node tiles, 32 channels at a time) instead of the 16-node-tile kernel.
  * Process-wide; for parity tests and same-process A/B timing.                                                       */
 int geobi_set_rowpass_form(int staged, int chunked64);
+/* column parts of the fused FeaSt kernel (16-row tiles, layers reading 128 channels): 2 = every tile is worked on by two
+ * workgroups, each producing half of the output columns; 1 = off; 0 = chosen per launch from the tile count (default: two parts
+ * up to 512 tiles; GEOBI_COLUMN_PARTS, GEOBI_COLUMN_PARTS_MAX_TILES).  Bit-identical results. */
+int geobi_set_column_parts(int parts);
 
 /* ---------------------------------------------------------------- pooling ------------------
  * geobi_edge_weight_t10 : PoolingLayer._get_edge_weight, edge_weight_type 10

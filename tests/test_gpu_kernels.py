@@ -166,6 +166,49 @@ def test_feast_conv_random_graph(dev, Cin, Cout, slope, split, fused):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize('Cin,Cout,split', [(64, 128, False), (64, 128, True), (128, 64, True), (128, 128, False),
+                                            (128, 32, False)])
+def test_feast_column_parts_are_bit_identical(dev, Cin, Cout, split):
+    """Launches of layers that read 128 channels (forward: Cin = 128; input gradient: Cout = 128) with at most 512 tiles
+    run every tile on TWO workgroups, each producing half of the output columns (feast_fused_kernel CS = 2,
+    geobi_set_column_parts).  A part runs
+    the unsplit kernel's accumulator chains, so forward, input gradient and every parameter gradient must agree with the
+    one-part launch bit for bit; the one-part launch is checked against the fp64 oracle here (the default -- two parts at
+    this size -- by every other test of this file)."""
+    from geobi_gnn_amd import _lib as L
+    from geobi_gnn_amd.feast_conv import FeaStConv
+    n = 333
+    g = torch.Generator().manual_seed(Cin + Cout)
+    ei = torch.cat([torch.randint(0, n - 20, (2, 3000), generator=g),
+                    torch.stack([torch.arange(1, 201), torch.zeros(200, dtype=torch.long)])], 1).to(dev)
+    torch.manual_seed(3)
+    conv = FeaStConv(Cin, Cout, 9).to(dev)
+    x = torch.randn(n, Cin, generator=g)
+    gout = torch.randn(n, Cout, generator=g).to(dev)
+    got = {}
+    try:
+        for parts in (1, 2):
+            L.call('geobi_set_column_parts', parts)
+            conv.zero_grad()
+            if split:
+                xa = x[:, :Cin // 2].to(dev).requires_grad_(True)
+                xb = x[:, Cin // 2:].to(dev).requires_grad_(True)
+                out = conv(xa, ei, x2=xb, slope=0.2)
+            else:
+                xa = x.to(dev).requires_grad_(True)
+                out = conv(xa, ei, slope=0.2)
+            out.backward(gout)
+            got[parts] = [out.detach().clone(), xa.grad.clone()] + ([xb.grad.clone()] if split else []) + \
+                         [p_.grad.clone() for p_ in conv.parameters()]
+            if parts == 1:
+                errs = _run_feast(dev, Cin, Cout, ei.cpu(), n, 0.2, split, seed=5)
+                assert max(errs.values()) < TOL, errs
+    finally:
+        L.call('geobi_set_column_parts', 0)
+    for a, b in zip(got[1], got[2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('Cout,slope,split', [(32, 0.2, False), (32, 1.0, True), (64, 0.2, True), (128, 0.2, False),
                                               (128, 1.0, True)])
 def test_feast_rowpass_forms_at_64_channels(dev, Cout, slope, split):
