@@ -263,6 +263,14 @@ int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32
   return edge_weight_t10(x, C, row, col, w_in, E, w_out, S(stream));
 }
 
+int geobi_edge_weight_att(const float* x, int C, const float* att_l, const float* att_r, const int32_t* row,
+                          const int32_t* col, const float* w_in, int64_t N, int64_t E, float* node_ws, float* w_out,
+                          void* stream) {
+  SIZES(N, E);
+  if (E > 0 && N > 0) { NOTNULL(x); NOTNULL(att_l); NOTNULL(att_r); NOTNULL(row); NOTNULL(col); NOTNULL(node_ws); NOTNULL(w_out); }
+  return edge_weight_att(x, C, att_l, att_r, row, col, w_in, N, E, node_ws, w_out, S(stream));
+}
+
 size_t geobi_match_ws_bytes(int64_t N) { return match_ws_bytes(N); }
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream) {

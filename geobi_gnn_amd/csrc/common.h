@@ -191,6 +191,8 @@ int concat32(const CopySeg* segs, int n_segs, int is_float, hipStream_t s);
 // pool.hip
 int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in, int64_t E,
                     float* w_out, hipStream_t s, int32_t* zero8 = nullptr);
+int edge_weight_att(const float* x, int C, const float* att_l, const float* att_r, const int32_t* row, const int32_t* col,
+                    const float* w_in, int64_t N, int64_t E, float* node_ws, float* w_out, hipStream_t s);
 int gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, hipStream_t s);
 int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s);
 size_t match_ws_bytes(int64_t N);

@@ -70,6 +70,53 @@ __global__ __launch_bounds__(256) void edge_weight_t10_kernel(const float* __res
   if (ok && l == 0) w_out[e] = (w_in ? w_in[e] : 0.f) + expf(d * -0.5f);
 }
 
+// Learned edge weights, PoolingLayer edge_weight_type 3 / 4 / 5 (/root/reference/code/net_util.py:182-206, GAT-style):
+// per node al = x . att_l, ar = x . att_r (8 lanes per node, float4 per lane and pass), per edge
+// sigmoid((al[r] + ar[c]) + (al[c] + ar[r])) in the reference's order of additions; type 5 averages with the given weight.
+__global__ __launch_bounds__(256) void node_att_kernel(const float* __restrict__ x, int C, const float* __restrict__ att_l,
+                                                       const float* __restrict__ att_r, int64_t N,
+                                                       float2* __restrict__ alr) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 3;
+  const int l = (int)(t & 7);
+  const bool ok = i < N;
+  float a = 0.f, b = 0.f;
+  if (ok) {
+    const float* xi = x + (size_t)i * C;
+    if ((C & 3) == 0) {
+      for (int c = l * 4; c < C; c += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(xi + c);
+        const float4 p = *reinterpret_cast<const float4*>(att_l + c);
+        const float4 q = *reinterpret_cast<const float4*>(att_r + c);
+        a = fmaf(v.x, p.x, a); a = fmaf(v.y, p.y, a); a = fmaf(v.z, p.z, a); a = fmaf(v.w, p.w, a);
+        b = fmaf(v.x, q.x, b); b = fmaf(v.y, q.y, b); b = fmaf(v.z, q.z, b); b = fmaf(v.w, q.w, b);
+      }
+    } else {
+      for (int c = l; c < C; c += 8) {
+        a = fmaf(xi[c], att_l[c], a);
+        b = fmaf(xi[c], att_r[c], b);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    a += __shfl_xor(a, m, 64);
+    b += __shfl_xor(b, m, 64);
+  }
+  if (ok && l == 0) alr[i] = make_float2(a, b);
+}
+
+__global__ __launch_bounds__(256) void edge_weight_att_kernel(const float2* __restrict__ alr, const int* __restrict__ row,
+                                                              const int* __restrict__ col, const float* __restrict__ w_in,
+                                                              int64_t E, float* __restrict__ w_out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float2 r = alr[row[e]], c = alr[col[e]];
+  const float alpha = (r.x + c.y) + (c.x + r.y);
+  const float sg = 1.0f / (1.0f + expf(-alpha));
+  w_out[e] = w_in != nullptr ? (sg + w_in[e]) * 0.5f : sg;
+}
+
 // ---------------------------------------------------------------------------- matching
 __device__ __forceinline__ bool edge_better(float w1, int a1, int b1, float w2, int a2, int b2) {
   // (a, b) = (min, max) endpoint ids
@@ -1118,6 +1165,17 @@ int edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* co
                     float* w_out, hipStream_t s, int32_t* zero8) {
   if (E <= 0) return 0;
   edge_weight_t10_kernel<<<cdiv(E * 8, 256), 256, 0, s>>>(x, C, row, col, w_in, E, w_out, zero8);
+  GEOBI_LAUNCH_OK();
+  return 0;
+}
+
+int edge_weight_att(const float* x, int C, const float* att_l, const float* att_r, const int32_t* row, const int32_t* col,
+                    const float* w_in, int64_t N, int64_t E, float* node_ws, float* w_out, hipStream_t s) {
+  if (E <= 0 || N <= 0) return 0;
+  if (C <= 0) return set_error("edge_weight_att: C = %d", C);
+  node_att_kernel<<<cdiv(N * 8, 256), 256, 0, s>>>(x, C, att_l, att_r, N, reinterpret_cast<float2*>(node_ws));
+  GEOBI_LAUNCH_OK();
+  edge_weight_att_kernel<<<cdiv(E, 256), 256, 0, s>>>(reinterpret_cast<const float2*>(node_ws), row, col, w_in, E, w_out);
   GEOBI_LAUNCH_OK();
   return 0;
 }

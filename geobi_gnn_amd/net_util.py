@@ -350,11 +350,24 @@ class PoolingLayer(nn.Module):
         if t == 2:
             return w * _feature_gauss(x, g, self.wei_param)
         if t in (3, 4, 5):
-            xx = x.detach() if t == 3 else F.leaky_relu(self.lin(x.detach()), 0.2)
-            al, ar = (xx * self.att_l).sum(-1), (xx * self.att_r).sum(-1)
-            r, c = g.ensure_rows().long(), g.col_out.long()
-            a = torch.sigmoid((al[r] + ar[c]) + (al[c] + ar[r])).detach()
-            return a if t in (3, 4) else (a + w) / 2
+            # learned (GAT-style) weights on the device: the Linear + leaky-relu of types 4 / 5 as one MFMA GEMM with
+            # its epilogue, the node dots and the per-edge sigmoid as geobi_edge_weight_att
+            xx = x.detach().contiguous()
+            n, c = xx.shape
+            if t != 3:
+                lw, lb = self.lin.weight.detach().contiguous(), self.lin.bias.detach().contiguous()
+                h = torch.empty(n, lw.shape[0], dtype=torch.float32, device=xx.device)
+                L.call('geobi_gemm_nn', L.ptr(xx), c, L.ptr(lw), c, 1, L.ptr(h), lw.shape[0], n, lw.shape[0], c, L.ptr(lb),
+                       0.2, L.stream())
+                xx, c = h, lw.shape[0]
+            if t == 5 and w is None:
+                raise L.GeobiError('edge_weight_type 5 averages with data.edge_weight, which is missing')
+            out = torch.empty(max(g.E, 1), dtype=torch.float32, device=xx.device)[:g.E]
+            ws = torch.empty(2 * n, dtype=torch.float32, device=xx.device)
+            L.call('geobi_edge_weight_att', L.ptr(xx), c, L.ptr(self.att_l.detach().reshape(-1).contiguous()),
+                   L.ptr(self.att_r.detach().reshape(-1).contiguous()), L.ptr(g.ensure_rows()), L.ptr(g.col_out),
+                   L.ptr(w) if t == 5 else None, n, g.E, L.ptr(ws), L.ptr(out), L.stream())
+            return out
         if t == 6:
             return _minmax(w)
         if t == 7:

@@ -160,3 +160,154 @@ class BestCheckpoint(object):
         if self.path:
             torch.save({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, self.path)
         return True
+
+
+# ------------------------------------------------------------------------------------------------ TensorBoard scalars
+# /root/reference/code/train_dual.py:134-136,222-226,262-266 logs through tensorboardX.SummaryWriter (add_scalar /
+# add_text).  tensorboardX is not a dependency here: the event-file format is small enough to write directly -- TFRecord
+# framing (length, masked CRC32-C of the length, payload, masked CRC32-C of the payload) around hand-encoded `Event` protobufs
+# (wall_time = 1: double, step = 2: varint, file_version = 3: string, summary = 5: { value = 1: { tag = 1: string,
+# simple_value = 2: float } }).  TensorBoard reads the files as it reads tensorboardX's.
+def _crc32c_table():
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        tab.append(c)
+    return tab
+
+
+_CRC_TAB = _crc32c_table()
+
+
+def _crc32c(data):
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC_TAB[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data):
+    c = _crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _field_bytes(num, payload):
+    return _varint((num << 3) | 2) + _varint(len(payload)) + payload
+
+
+class SummaryWriter(object):
+    """The subset of tensorboardX.SummaryWriter the reference's driver uses: ``add_scalar(tag, value, step)``,
+    ``add_text(tag, text)`` (kept as a ``<tag>.txt`` file beside the events: the text plugin's tensor encoding is not
+    reproduced), ``flush()``, ``close()``; one ``events.out.tfevents.<time>.<host>`` file per writer in ``log_dir``."""
+
+    def __init__(self, log_dir):
+        import os, socket, struct, time
+        self._struct, self._time = struct, time
+        os.makedirs(log_dir, exist_ok=True)
+        self.log_dir = log_dir
+        self.path = os.path.join(log_dir, 'events.out.tfevents.%010d.%s' % (int(time.time()), socket.gethostname()))
+        self._f = open(self.path, 'wb')
+        self._event(_field_bytes(3, b'brain.Event:2'), step=None)
+
+    def _event(self, body, step):
+        s = self._struct
+        ev = b'\x09' + s.pack('<d', self._time.time())
+        if step is not None:
+            ev += b'\x10' + _varint(int(step))
+        ev += body
+        head = s.pack('<Q', len(ev))
+        self._f.write(head + s.pack('<I', _masked_crc(head)) + ev + s.pack('<I', _masked_crc(ev)))
+
+    def add_scalar(self, tag, value, global_step=0):
+        val = _field_bytes(1, str(tag).encode('utf-8')) + b'\x15' + self._struct.pack('<f', float(value))
+        self._event(_field_bytes(5, _field_bytes(1, val)), global_step)
+
+    def add_text(self, tag, text, global_step=0):
+        import os
+        with open(os.path.join(self.log_dir, '%s.txt' % str(tag).replace('/', '_')), 'w') as f:
+            f.write(str(text))
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        if not self._f.closed:
+            self._f.close()
+
+
+def read_scalars(path):
+    """[(step, tag, value)] of an event file written by SummaryWriter (or tensorboardX): checks the record CRCs and decodes
+    the scalar summaries -- the reader half of the format, for tests and for tools that plot without TensorBoard."""
+    import struct
+
+    def varint(buf, i):
+        v, sh = 0, 0
+        while True:
+            b = buf[i]; i += 1
+            v |= (b & 0x7F) << sh; sh += 7
+            if not b & 0x80:
+                return v, i
+
+    def fields(buf):
+        i = 0
+        while i < len(buf):
+            key, i = varint(buf, i)
+            num, wt = key >> 3, key & 7
+            if wt == 0:
+                v, i = varint(buf, i)
+            elif wt == 1:
+                v = buf[i:i + 8]; i += 8
+            elif wt == 5:
+                v = buf[i:i + 4]; i += 4
+            elif wt == 2:
+                n, i = varint(buf, i)
+                v = buf[i:i + n]; i += n
+            else:
+                raise ValueError('wire type %d' % wt)
+            yield num, wt, v
+
+    out = []
+    data = open(path, 'rb').read()
+    i = 0
+    while i < len(data):
+        head = data[i:i + 8]
+        n, = struct.unpack('<Q', head)
+        if struct.unpack('<I', data[i + 8:i + 12])[0] != _masked_crc(head):
+            raise ValueError('length CRC mismatch at byte %d' % i)
+        ev = data[i + 12:i + 12 + n]
+        if struct.unpack('<I', data[i + 12 + n:i + 16 + n])[0] != _masked_crc(ev):
+            raise ValueError('payload CRC mismatch at byte %d' % i)
+        i += 16 + n
+        step, summary = 0, None
+        for num, wt, v in fields(ev):
+            if num == 2 and wt == 0:
+                step = v
+            elif num == 5 and wt == 2:
+                summary = v
+        if summary is None:
+            continue
+        for num, wt, v in fields(summary):
+            if num != 1:
+                continue
+            tag, val = None, None
+            for n2, w2, v2 in fields(v):
+                if n2 == 1:
+                    tag = bytes(v2).decode('utf-8')
+                elif n2 == 2 and w2 == 5:
+                    val, = struct.unpack('<f', v2)
+            if tag is not None and val is not None:
+                out.append((step, tag, val))
+    return out

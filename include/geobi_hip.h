@@ -171,6 +171,13 @@ int geobi_set_column_parts(int parts);
  *                         E entries / nmax+1 row pointers; count[0] = kept edges (device int32).   */
 int geobi_edge_weight_t10(const float* x, int C, const int32_t* row, const int32_t* col, const float* w_in,
                           int64_t E, float* w_out, void* stream);
+/* geobi_edge_weight_att: PoolingLayer._get_edge_weight, edge_weight_type 3 / 4 / 5 (code/net_util.py:182-206): the
+ * GAT-style learned weight  sigmoid((al[row] + ar[col]) + (al[col] + ar[row])),  al = x . att_l,  ar = x . att_r  per node
+ * (x [N, C]: the features for type 3, leaky_relu(lin(x), 0.2) for types 4 / 5 -- geobi_gemm_nn with bias and slope);
+ * w_in != NULL: averaged with the given weight, (sigmoid + w_in) / 2 (type 5).  node_ws: 2 N floats of scratch.          */
+int geobi_edge_weight_att(const float* x, int C, const float* att_l, const float* att_r, const int32_t* row,
+                          const int32_t* col, const float* w_in, int64_t N, int64_t E, float* node_ws, float* w_out,
+                          void* stream);
 size_t geobi_match_ws_bytes(int64_t N);
 int geobi_match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int rounds,
                            int init, int32_t* cluster, int32_t* cluster_final, int32_t* status, void* ws, size_t ws_bytes, void* stream);

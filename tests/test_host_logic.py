@@ -586,3 +586,31 @@ def test_flat_adam_refuses_options_it_does_not_implement():
         p.grad = torch.ones(4)
         with pytest.raises(ValueError, match=list(kw)[0]):
             opt.step()
+
+
+def test_tensorboard_event_writer_round_trip(tmp_path):
+    """train_util.SummaryWriter stands in for tensorboardX (train_dual.py:134-136,222-226; not installed here, nor is
+    TensorBoard: the format is pinned by the CRC-32C known answer of RFC 3720, the TFRecord framing constants and the
+    module's own reader, which checks both CRCs of every record)."""
+    import struct
+    from geobi_gnn_amd import train_util as T
+    assert T._crc32c(b'123456789') == 0xE3069283
+    assert T._crc32c(bytes(32)) == 0x8A9136AA              # RFC 3720 B.4: 32 bytes of zeros
+    w = T.SummaryWriter(str(tmp_path / 'train'))
+    want = []
+    for it in range(1, 40):
+        for tag, v in (('loss_v', 0.5 / it), ('error_f', 30.0 / it), ('dual_loss', -1.25e-3 * it)):
+            w.add_scalar(tag, v, it * 4)
+            want.append((it * 4, tag, struct.unpack('<f', struct.pack('<f', v))[0]))
+    w.add_text('train_params', 'Namespace(lr=0.001)')
+    w.close()
+    assert T.read_scalars(w.path) == want
+    assert (tmp_path / 'train' / 'train_params.txt').read_text() == 'Namespace(lr=0.001)'
+    raw = open(w.path, 'rb').read()
+    n, = struct.unpack('<Q', raw[:8])
+    assert raw[12:12 + n].endswith(b'brain.Event:2')        # the file-version record comes first
+    broken = bytearray(raw); broken[40] ^= 1
+    bad = tmp_path / 'broken'
+    bad.write_bytes(bytes(broken))
+    with pytest.raises(ValueError):
+        T.read_scalars(str(bad))

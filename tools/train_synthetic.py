@@ -35,6 +35,8 @@ def parse_arguments(argv=None):
     p.add_argument('--rotate', type=int, default=0, help='1: random z rotation per batch, 2: full 3-axis (dataset.py:39-69)')
     p.add_argument('--seed', type=int, default=40938661)
     p.add_argument('--out', type=str, default='')
+    p.add_argument('--tb_dir', type=str, default='', help='TensorBoard event files: <tb_dir>/train (per iteration) and <tb_dir>/test '
+                   '(per epoch), the scalars of train_dual.py:222-226,262-266 (train_util.SummaryWriter)')
     return p.parse_args(argv)
 
 
@@ -64,10 +66,18 @@ def main(argv=None):
     import numpy as np
     rotate = None if not opt.rotate else RandomRotate(z_rotated=opt.rotate == 1, rng=np.random.default_rng(opt.seed + rank))
     best, history = math.inf, []
+    train_writer = test_writer = None
+    if opt.tb_dir and rank == 0:
+        import os
+        train_writer = train_util.SummaryWriter(os.path.join(opt.tb_dir, 'train'))
+        test_writer = train_util.SummaryWriter(os.path.join(opt.tb_dir, 'test'))
+        test_writer.add_text('train_params', str(opt))
+    iteration = 0
     for epoch in range(1, opt.max_epoch + 1):
         net.train()
         mine = shard_indices(len(train), rank, world, seed=opt.seed, epoch=epoch)
         t0 = time.time()
+        pending = []
         for s in range(0, len(mine), opt.batch_size):
             dv, df = union_batch_graphs([train[i] for i in mine[s:s + opt.batch_size]])
             if rotate is not None:
@@ -79,6 +89,18 @@ def main(argv=None):
             loss.backward()
             flat.bucket.all_reduce_mean()
             optimizer.step()
+            iteration += len(mine[s:s + opt.batch_size])
+            if train_writer is not None:
+                # the reference reads five scalars back per iteration (.item()); here they stay on the device until the
+                # epoch ends -- one host read per epoch instead of one per step
+                with torch.no_grad():
+                    pending.append((iteration, torch.stack([lv.detach(), ln.detach(), loss.detach(),
+                                                            network.error_v(vp.detach(), dv.y), network.error_n(npred.detach(), df.y)])))
+        if train_writer is not None:
+            for it, vals in pending:
+                for tag, v in zip(('loss_v', 'loss_f', 'dual_loss', 'error_v', 'error_f'), vals.tolist()):
+                    train_writer.add_scalar(tag, v, it)
+            train_writer.flush()
         # evaluation: node-count-weighted means over the eval meshes of every rank (train_dual.py:233-259)
         net.eval()
         meter = train_util.EvalMeter()
@@ -95,7 +117,14 @@ def main(argv=None):
         saved = ckpt.update(net, rec['eval_error_f_deg'])     # keys: gnn_v.l_conv1.lin.weight ... fc_f2.bias
         if rank == 0:
             print(json.dumps(dict(rec, saved=saved)), flush=True)
+        if test_writer is not None:
+            for tag, key in (('loss_v', 'eval_loss_v'), ('loss_f', 'eval_loss_f'), ('error_v', 'eval_error_v'), ('error_f', 'eval_error_f')):
+                test_writer.add_scalar(tag, res[key], iteration)
+            test_writer.flush()
         train_util.step_scheduler(opt, sch, rec['eval_error_f_deg'])
+    for w in (train_writer, test_writer):
+        if w is not None:
+            w.close()
     return history
 
 
