@@ -742,6 +742,13 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = xcd_block(blockIdx.x, gridDim.x);
   if (tile * TN >= N) return;
+#ifdef GEOBI_FUSED_STAMPS
+  // diagnostic build: cycles of thread 0 per phase, summed over the channel chunks (tools/rp128_stamps.py)
+  unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_acc[4] = {0, 0, 0, 0};
+#define GEOBI_RP128_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; } } while (0)
+#else
+#define GEOBI_RP128_MARK(i) do { } while (0)
+#endif
 
   // ---- g tile (as in the kernel above)
   {
@@ -777,43 +784,61 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
 #pragma unroll
   for (int h = 0; h < H; ++h) sv0[h] = 0.f;
   const int j0 = k < deg ? col[rs + k] : ns;                   // the first 16 items' neighbour, kept across the chunks
-  __syncthreads();
 
   const int hf = lane >> 5, l31 = lane & 31;
+  // Matrix-phase weights: head t's rows of Wf for this channel chunk, COUT / 8 float4 per lane.  Cout <= 64: all of a
+  // chunk's (<= 8) are requested at once BEFORE the barrier that ends the previous chunk's row pass (before the g-tile
+  // barrier for chunk 0) -- one round trip per chunk, mostly under the barrier: 111.3 -> 108.6 us at 712 tiles.  Cout = 128
+  // (16 per chunk): batches of four as before; a ring of 8 with pinned refills measured 57 -> 86 us there (the scheduler
+  // already moves a batch's loads above the previous batch's MFMAs where it pays; profiles/r04_weight_ring.txt).
+  // tools/rp128_stamps.py: the matrix phases are 26-32 k of a tile's 58 k cycles at 128 -> 64 -- the nine dz tiles of a
+  // chunk are 18 k wave-cycles of MFMA per SIMD and tile, shared with the other resident workgroup's row pass.
   constexpr int NKB = COUT / 8, HB = 4;
+  constexpr bool AHEAD = NKB <= 8;
   static_assert(NKB % HB == 0, "whole weight batches");
+  float4 wa[AHEAD ? NKB : 1];
+  auto issue_w = [&](int cc) {
+    if constexpr (AHEAD) {
+      const float* brow = Wf + (size_t)(wave * C + cc * CCH + l31) * COUT + 4 * hf;
+#pragma unroll
+      for (int u = 0; u < NKB; ++u) wa[u] = *reinterpret_cast<const float4*>(brow + 8 * u);
+    }
+  };
+  issue_w(0);
+  __syncthreads();
+  GEOBI_RP128_MARK(0);
+
   static_for<0, NCC>([&](auto cci) {
     constexpr int cc = decltype(cci)::value;
-    // ---- matrix phase: head h's 32 columns of this channel chunk = dz tile h = wave h's
+    // ---- matrix phase: head h's 32 columns of this channel chunk = dz tile h = wave h's (nine waves, nine heads)
     {
       const float* arow = s_g + l31 * GL + 4 * hf;
-      {
-        const int t = wave;                                    // nine waves, nine heads
-        {
-          const float* brow = Wf + (size_t)(t * C + cc * CCH + l31) * COUT + 4 * hf;
-          f32x16 acc;
+      const float* brow = Wf + (size_t)(wave * C + cc * CCH + l31) * COUT + 4 * hf;
+      f32x16 acc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-          for (int b0 = 0; b0 < NKB; b0 += HB) {
-            float4 wv[HB];
+      for (int b0 = 0; b0 < NKB; b0 += HB) {
+        float4 wv[HB];
 #pragma unroll
-            for (int u = 0; u < HB; ++u) wv[u] = *reinterpret_cast<const float4*>(brow + 8 * (b0 + u));
+        for (int u = 0; u < HB; ++u) {
+          if constexpr (AHEAD) wv[u] = wa[b0 + u];
+          else wv[u] = *reinterpret_cast<const float4*>(brow + 8 * (b0 + u));
+        }
 #pragma unroll
-            for (int u = 0; u < HB; ++u) {
-              const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + t * 32 + l31] = acc[r];
+        for (int u = 0; u < HB; ++u) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + 8 * (b0 + u));
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_z[((r & 3) + 8 * (r >> 2) + 4 * hf) * LDZ + wave * 32 + l31] = acc[r];
     }
     __syncthreads();
+    GEOBI_RP128_MARK(1);
     // ---- this chunk's share of the dot products, lane = item; every lane of a group runs the FMAs (row broadcasts)
     {
       float dzr[NSLOT][4];
@@ -868,7 +893,12 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
         }
       }
     }
-    if constexpr (cc + 1 < NCC) __syncthreads();               // the next chunk overwrites the dz tile
+    if constexpr (cc + 1 < NCC) {
+      if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);  // not earlier: the row pass needs its registers
+      issue_w(cc + 1);                                         // in flight across the barrier
+      __syncthreads();                                         // the next chunk overwrites the dz tile
+    }
+    GEOBI_RP128_MARK(2);
   });
 
   // ---- softmax backward with the complete dot products
@@ -930,6 +960,11 @@ __global__ __launch_bounds__(KT9, 5) void feast_rowpass_fused128_kernel(
     dsum[h] = group_allreduce<G>(dsum[h]);
     dself[h] = group_allreduce<G>(self ? d[h] : 0.f);
   }
+#ifdef GEOBI_FUSED_STAMPS
+  GEOBI_RP128_MARK(3);
+  if (threadIdx.x == 0 && blockIdx.x < 16384)
+    for (int i = 0; i < 4; ++i) g_stamps_bwd[blockIdx.x][i] = t_acc[i];
+#endif
   if (!valid || k != 0) return;
   float4* a4 = reinterpret_cast<float4*>(dpn + (size_t)node * HP);
   a4[0] = make_float4(dsum[0], dsum[1], dsum[2], dsum[3]);
