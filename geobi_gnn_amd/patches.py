@@ -301,6 +301,77 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     return out
 
 
+def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data_type='Synthetic', patch_batch=5):
+    """test_dual.py:90-148 (predict_dir) over a list of meshes with the SMALL ones -- at most ``sub_size`` faces, one
+    network pass each in the reference -- going through the network and the vertex update several at a time, as one
+    disjoint-union mesh of up to ``max_faces`` faces (in list order).  A single n = 32 mesh is a chain of
+    ~110 launches and four size reads that takes 1.0 ms whatever its size (a 7 x larger mesh takes 2.1 ms): the union
+    fills those launches.  Components do not interact -- graph construction and the weights stay per mesh, the network's
+    rows are independent per component (tests/test_gpu_model.py: test_full_size_properties), the vertex update walks each
+    vertex's own faces -- so every mesh gets the bits ``predict_mesh`` gives it alone (tests/test_gpu_patches.py).  Meshes
+    above ``sub_size`` go through ``predict_mesh`` (patch split) one by one.
+    meshes: list of (points, faces) or (points, faces, gt_points) -> list of predict_mesh's result dicts, in order."""
+    dev = next(net.parameters()).device
+    results = [None] * len(meshes)
+    group, faces_in_group = [], 0
+
+    def flush():
+        if not group:
+            return
+        duals = [g[3] for g in group]
+        if len(group) == 1:
+            dual, vr, fr = duals[0], [(0, group[0][1].shape[0])], [(0, group[0][2].shape[0])]
+        else:
+            dual, vr, fr = _union_dual(duals)
+        Vp, Np = predict_one_submesh(net, dual)      # owned copies of the arena's results
+        for (i, pts, fv, d, gt), (v0, v1) in zip(group, vr):
+            meta = d[0].meta
+            Vp[v0:v1] = Vp[v0:v1] / meta['scale'] + meta['centroid']
+        if len(group) == 1:
+            fv_u, vf_u, pts_u = group[0][2], group[0][3][0].meta['vf_indices'], group[0][1]
+        else:
+            from .data import _Concat
+            cc = _Concat(dev)
+            fv_u = cc.cat([g[2].view(-1) for g in group], [v0 for v0, _ in vr]).view(-1, 3)
+            cc.run()
+            rowptr, lst = meshprep.vertex_faces(fv_u, Vp.shape[0])
+            vf_u = meshprep.vf_padded32(rowptr, lst, Vp.shape[0])
+            pts_u = None
+        dd = None
+        if data_type in ('Kinect_v1', 'Kinect_v2'):
+            dd = torch.nn.functional.normalize(torch.cat([g[1] for g in group]) if pts_u is None else pts_u, dim=1)
+        Vu = update_position2(Vp, fv_u, vf_u, Np, n_iter=n_iter, depth_direction=dd)
+        for (i, pts, fv, d, gt), (v0, v1), (f0, f1) in zip(group, vr, fr):
+            out = {'Vp': Vp[v0:v1], 'Np': Np[f0:f1], 'V_updated': Vu[v0:v1], 'n_patches': 1, 'angle1': None, 'angle2': None}
+            if gt is not None:
+                g_ = torch.as_tensor(np.asarray(gt) if not torch.is_tensor(gt) else gt).to(device=dev, dtype=torch.float32).contiguous()
+                Nt = computer_face_normal(g_, fv)
+                out['angle1'] = float(network.error_n(out['Np'], Nt))
+                out['angle2'] = float(network.error_n(computer_face_normal(out['V_updated'], fv), Nt))
+            results[i] = out
+        del group[:]
+
+    for i, m in enumerate(meshes):
+        gt = m[2] if len(m) > 2 else None
+        pts = torch.as_tensor(np.asarray(m[0]) if not torch.is_tensor(m[0]) else m[0]).to(device=dev, dtype=torch.float32).contiguous()
+        fv = torch.as_tensor(np.asarray(m[1]) if not torch.is_tensor(m[1]) else m[1]).to(device=dev, dtype=torch.int32).contiguous()
+        F = fv.shape[0]
+        if F > sub_size or F == 0:              # the group stays open: results are placed by index
+            kw = {} if gt is None else {'gt_points': gt}
+            results[i] = predict_mesh(net, pts, fv, sub_size=sub_size, n_iter=n_iter, data_type=data_type,
+                                      patch_batch=patch_batch, distributed=False, **kw)
+            continue
+        if group and faces_in_group + F > max_faces:
+            flush()
+            faces_in_group = 0
+        # the caller's face table is range-checked inside build_dual_data before any kernel walks it
+        dual = meshprep.build_dual_data(pts, fv, name='mesh', data_type=data_type, device=dev)
+        group.append((i, pts, fv, dual, gt))
+        faces_in_group += F
+    flush()
+    return results
+
+
 _POOLS = {}          # workers -> ThreadPoolExecutor: the worker threads (= library contexts: mailbox, scan state, side streams,
 _TLS = None          # growth stream) live as long as the process, so repeated calls allocate nothing new
 

@@ -401,3 +401,28 @@ def test_meshes_in_flight_together_equal_one_by_one(dev):
             for g, w in zip(got, want):
                 assert g['n_patches'] == w['n_patches']
                 assert torch.equal(g['Np'], w['Np']) and torch.equal(g['V_updated'], w['V_updated'])
+
+
+def test_predict_batch_equals_mesh_by_mesh(dev):
+    """patches.predict_batch: the small meshes of a list go through the network and the vertex update as one disjoint-union
+    mesh (a group is closed when it would pass max_faces), the large ones through the patch split; every mesh must get the
+    bits predict_mesh gives it alone -- predictions, updated vertices and both angular errors."""
+    from geobi_gnn_amd import network, meshgen, patches
+    torch.manual_seed(5)
+    net = network.DualGNN().to(dev).eval()
+    meshes = []
+    for i, n in enumerate((8, 10, 14, 9, 12, 8, 11)):
+        noisy, clean, faces = meshgen.noisy_icosphere(n, (0.1, 0.2, 0.3)[i % 3], seed=600 + i)
+        meshes.append((torch.as_tensor(noisy, dtype=torch.float32, device=dev),
+                       torch.as_tensor(faces, dtype=torch.int32, device=dev),
+                       torch.as_tensor(clean, dtype=torch.float32, device=dev)))
+    with torch.no_grad():
+        want = [patches.predict_mesh(net, p, f, sub_size=3000, n_iter=10, gt_points=g) for p, f, g in meshes]
+        got = patches.predict_batch(net, meshes, max_faces=6000, sub_size=3000, n_iter=10)
+        one = patches.predict_batch(net, meshes[:1], sub_size=3000, n_iter=10)
+    assert [w['n_patches'] for w in want] == [g['n_patches'] for g in got]
+    assert want[2]['n_patches'] > 1                       # n = 14: 3 920 faces, split
+    for w, g in zip(want + want[:1], got + one):
+        for k in ('Vp', 'Np', 'V_updated'):
+            assert torch.equal(w[k], g[k]), k
+        assert w['angle1'] == g['angle1'] and w['angle2'] == g['angle2']
