@@ -373,14 +373,15 @@ def measure_test_list(net, device, sub_size=20000):
         patches.predict_many(net, lst, workers=workers, sub_size=sub_size, n_iter=60)
         torch.cuda.synchronize()
         many['workers_%d' % workers] = round((time.perf_counter() - t1) * 1e3, 2)
-    # the same list with the small meshes (<= sub_size faces) as disjoint unions of up to 100 000 faces (patches.predict_batch)
+    # the same list through patches.predict_batch: the small meshes (<= sub_size faces) as disjoint unions of up to 100 000
+    # faces, the patch-split ones four at a time (growth chains side by side, passes of up to 12 pooled patches)
     patches.predict_batch(net, meshes, max_faces=100000, sub_size=sub_size, n_iter=60)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for _ in range(reps):
         patches.predict_batch(net, meshes, max_faces=100000, sub_size=sub_size, n_iter=60)
     torch.cuda.synchronize()
     batched = (time.perf_counter() - t1) / reps
-    log('test list with 2 / 4 meshes in flight: %s ms; small meshes as unions: %.1f ms' % (many, batched * 1e3))
+    log('test list with 2 / 4 meshes in flight: %s ms; batched (predict_batch): %.1f ms' % (many, batched * 1e3))
     log('test list: %.1f ms for 29 meshes (%d patch-split), %.1f M-edges/s' % (dt * 1e3, n_split, edges / dt / 1e6))
     return {'workload': 'Synthetic test_list stand-in: 29 noisy icospheres n in {16,22,32,45} x 3 noise levels through '
                         'patches.predict_mesh (preprocessing, patch split at %d faces, network, merge, 60-sweep vertex '
@@ -388,11 +389,12 @@ def measure_test_list(net, device, sub_size=20000):
             'total_ms': round(dt * 1e3, 2), 'meshes_per_s': round(29 / dt, 1), 'M_edges_per_s': round(edges / dt / 1e6, 1),
             'level0_edges': edges, 'faces': sum(f.shape[0] for _, f, _ in meshes), 'patch_split_meshes': n_split,
             'meshes_in_flight_total_ms': many,
-            'small_meshes_as_unions': {'total_ms': round(batched * 1e3, 2), 'meshes_per_s': round(29 / batched, 1),
-                                       'M_edges_per_s': round(edges / batched / 1e6, 1),
-                                       'note': 'patches.predict_batch: the 15 meshes below the patch size through the network '
-                                               'and the vertex update as disjoint unions of <= 100 000 faces (bit-identical '
-                                               'per mesh); the 14 patch-split ones as above'},
+            'batched': {'total_ms': round(batched * 1e3, 2), 'meshes_per_s': round(29 / batched, 1),
+                        'M_edges_per_s': round(edges / batched / 1e6, 1),
+                        'note': 'patches.predict_batch: the 15 meshes below the patch size through the network and the vertex '
+                                'update as disjoint unions of <= 100 000 faces; the 14 patch-split ones four at a time (growth '
+                                'chains side by side, network passes of <= 12 pooled patches, one vertex update per group); '
+                                'per-mesh results bit-identical to the mesh-by-mesh run above'},
             'share_outside_network': round(1.0 - stats.get('network', 0.0) / tot, 3),
             'phase_ms_synchronised': {k: round(v * 1e3, 2) for k, v in stats.items()},
             'phase_note': 'one extra pass with a device sync behind every phase: upper bounds of the overlapped costs'}

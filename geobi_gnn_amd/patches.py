@@ -26,10 +26,11 @@ from .infer import predict_one_submesh
 _GROW_STREAMS = {}
 
 
-def _grow_stream(dev):
-    """One side stream per device for the growth chain: it runs beside the patches' own work on the caller's stream."""
+def _grow_stream(dev, slot=0):
+    """One side stream per device for the growth chain: it runs beside the patches' own work on the caller's stream.
+    slot: further chains of the same host thread (predict_batch grows the patches of several meshes at once)."""
     import threading
-    key = (dev.type, dev.index, threading.get_ident())           # one chain per host thread (predict_many keeps its threads)
+    key = (dev.type, dev.index, threading.get_ident(), slot)     # one chain per host thread (predict_many keeps its threads)
     if key not in _GROW_STREAMS:
         _GROW_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _GROW_STREAMS[key]
@@ -301,7 +302,168 @@ def predict_mesh(net, points, faces, sub_size=20000, n_iter=60, data_type='Synth
     return out
 
 
-def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data_type='Synthetic', patch_batch=5):
+class _SplitJob(object):
+    """One mesh above the patch size inside predict_batch: its whole-mesh preprocessing, its growth chain (ALL launches of
+    the chain enqueued at once on a stream of its own, sizes through its share of the thread's mailbox) and the sums its
+    patches are merged into -- predict_mesh's split branch cut into steps, so that several meshes can take them together."""
+
+    def __init__(self, index, pts, fv, gt):
+        self.index, self.pts, self.fv, self.gt = index, pts, fv, gt
+        self.V, self.F = int(pts.shape[0]), int(fv.shape[0])
+
+    def prepare(self):
+        rowptr, lst = meshprep.vertex_faces(self.fv, self.V)
+        self.incidence = (rowptr, lst)
+        self.vf32 = meshprep.vf_padded32(rowptr, lst, self.V)
+        g_v = meshprep.ring_graph(0, self.fv, rowptr, lst, self.V)
+        self.centroid = self.pts.mean(0, keepdim=True)
+        self.host_words = torch.cat([meshprep.mean_edge_length(self.pts, g_v), self.centroid.reshape(-1)])
+
+    def normalisation(self, host):
+        self.scale, self.c = float(1.0 / torch.tensor(host[0], dtype=torch.float32)), host[1:]
+
+    def start_chain(self, sub_size, box_ptr, ahead, slot):
+        dev = self.fv.device
+        self.sub = int(min(sub_size, self.F))
+        self.ahead, self.box_ptr = ahead, box_ptr
+        d2 = ((self.pts[self.fv.long()].mean(1) - self.centroid) ** 2).sum(1).contiguous()
+        state = torch.empty(L.size_query('geobi_patch_grow_state_ints', self.F, self.V), dtype=torch.int32, device=dev)
+        L.call('geobi_patch_grow_init', L.ptr(state), self.F, self.V, L.ptr(d2), L.stream())
+        main, gs = torch.cuda.current_stream(dev), _grow_stream(dev, slot)
+        gs.wait_stream(main)
+        self.gs, self.events = gs, []
+        with torch.cuda.stream(gs):
+            self.slab = torch.empty(ahead * self.sub, dtype=torch.int32, device=dev)
+            for i in range(ahead):
+                L.call('geobi_patch_grow', L.ptr(self.fv), L.ptr(self.vf32), int(self.vf32.shape[1]), self.F, self.V, L.ptr(d2),
+                       -1, self.sub, 0, i + 1, L.ptr(state), self.slab.data_ptr() + 4 * i * self.sub, None, box_ptr + 4 * i, 1,
+                       gs.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(gs)
+                self.events.append(ev)
+        self.slab.record_stream(main)
+        self._keep = (d2, state)
+
+    def collect(self):
+        """-> the patches' face lists (waits for the chain), or None when the chain needs more launches than were enqueued
+        (the caller then takes the mesh through predict_mesh)."""
+        main = torch.cuda.current_stream(self.fv.device)
+        sels = []
+        for i in range(self.ahead):
+            word = L.lib().geobi_host_mailbox_wait(ctypes.c_void_p(self.box_ptr + 4 * i), ctypes.c_void_p(self.gs.cuda_stream))
+            if word == 0:
+                raise L.GeobiError('patch growth: the chain ended without reporting patch %d' % i)
+            n = (word - 1) // 2
+            if n == 0:
+                return sels
+            main.wait_event(self.events[i])
+            sels.append(self.slab[i * self.sub:i * self.sub + n])
+        return None
+
+    def sums(self):
+        dev = self.fv.device
+        self.Vp = torch.zeros((self.V, 3), dtype=torch.float32, device=dev)
+        self.Np = torch.zeros((self.F, 3), dtype=torch.float32, device=dev)
+        self.sum_v = torch.zeros(self.V, dtype=torch.int32, device=dev)
+
+
+def _predict_split_group(net, jobs, results, sub_size, n_iter, data_type, patch_batch):
+    """predict_mesh's patch-split branch for SEVERAL meshes at once (patches.predict_batch): the meshes' growth chains run
+    beside one another (a chain is one workgroup per launch), their normalisation constants come back in one read, a network
+    pass takes patches of any of them (per mesh one build_patch_union, then the union of those), and the vertex update runs
+    once over the union of the meshes.  Every mesh gets the bits predict_mesh gives it alone."""
+    dev = jobs[0].fv.device
+    for j in jobs:
+        j.prepare()
+    host = torch.cat([j.host_words for j in jobs]).tolist()              # one read for all of them
+    aheads = [int(min(32, 2 * ((j.F + sub_size - 1) // sub_size) + 2)) for j in jobs]
+    box = ctypes.c_void_p(0)
+    L.call('geobi_host_mailbox', sum(aheads), ctypes.byref(box))
+    off = 0
+    try:
+        for slot, (j, a) in enumerate(zip(jobs, aheads)):
+            j.normalisation(host[4 * slot:4 * slot + 4])
+            j.start_chain(sub_size, box.value + 4 * off, a, slot)
+            off += a
+        live, pending, general = [], [], []
+        collected = [(j, j.collect()) for j in jobs]                     # every chain's words are read before the mailbox is reused
+        for j, sels in collected:
+            if sels is None:                                             # more patches than launches: the general path, below
+                general.append(j)
+                continue
+            j.sums()
+            j.n_patches = len(sels)
+            live.append(j)
+            pending += [(j, sel) for sel in sels]
+        # ---- network passes over the pooled patches, in order
+        step = max(1, int(patch_batch))
+        for p0 in range(0, len(pending), step):
+            chunk = pending[p0:p0 + step]
+            owners = []
+            for j, _ in chunk:
+                if j not in owners:
+                    owners.append(j)
+            parts = []
+            for j in owners:
+                sels = [sel for jj, sel in chunk if jj is j]
+                dual, v_idxs, vr, fr = build_patch_union(j.pts, j.fv, sels, j.centroid, j.scale, data_type)
+                parts.append((j, sels, dual, v_idxs, vr, fr))
+            if len(parts) == 1:
+                dual, voff, foff = parts[0][2], [0], [0]
+            else:
+                dual, vrs, frs = _union_dual([pt[2] for pt in parts])
+                voff, foff = [v0 for v0, _ in vrs], [f0 for f0, _ in frs]
+            vert_p, norm_p = predict_one_submesh(net, dual)
+            for (j, sels, _, v_idxs, vr, fr), vo, fo in zip(parts, voff, foff):
+                for sel, v_idx, (v0, v1), (f0, f1) in zip(sels, v_idxs, vr, fr):
+                    L.call('geobi_patch_accumulate', L.ptr(vert_p[vo + v0:vo + v1]), L.ptr(norm_p[fo + f0:fo + f1]), L.ptr(v_idx),
+                           L.ptr(sel), v_idx.shape[0], sel.shape[0], L.ptr(j.Vp), L.ptr(j.Np), L.ptr(j.sum_v), L.stream())
+        for j in live:
+            L.call('geobi_patch_finalize', L.ptr(j.Vp), L.ptr(j.Np), L.ptr(j.sum_v), j.V, j.F, j.scale, j.c[0], j.c[1], j.c[2],
+                   L.stream())
+        for j in general:
+            j.gs.synchronize()
+            kw = {} if j.gt is None else {'gt_points': j.gt}
+            results[j.index] = predict_mesh(net, j.pts, j.fv, sub_size=sub_size, n_iter=n_iter, data_type=data_type,
+                                            patch_batch=patch_batch, distributed=False, **kw)
+        if not live:
+            return
+        # ---- one vertex update over the union of the meshes (each vertex walks its own faces: same bits as per mesh)
+        if len(live) == 1:
+            j = live[0]
+            Vp_u, Np_u, fv_u, vf_u = j.Vp, j.Np, j.fv, j.vf32
+            vptr, fptr = [0, j.V], [0, j.F]
+        else:
+            vptr, fptr = [0], [0]
+            for j in live:
+                vptr.append(vptr[-1] + j.V); fptr.append(fptr[-1] + j.F)
+            W = max(int(j.vf32.shape[1]) for j in live)
+            Vp_u, Np_u = torch.cat([j.Vp for j in live]), torch.cat([j.Np for j in live])
+            fv_u = torch.cat([j.fv + v0 for j, v0 in zip(live, vptr)])
+            vf_u = torch.full((vptr[-1], W), -1, dtype=torch.int32, device=dev)
+            for j, v0, f0 in zip(live, vptr, fptr):
+                w = int(j.vf32.shape[1])
+                vf_u[v0:v0 + j.V, :w] = torch.where(j.vf32 >= 0, j.vf32 + f0, j.vf32)
+        dd = None
+        if data_type in ('Kinect_v1', 'Kinect_v2'):
+            dd = torch.nn.functional.normalize(torch.cat([j.pts for j in live]), dim=1)
+        Vu = update_position2(Vp_u, fv_u, vf_u, Np_u, n_iter=n_iter, depth_direction=dd)
+        for j, v0, f0 in zip(live, vptr, fptr):
+            out = {'Vp': j.Vp, 'Np': j.Np, 'V_updated': Vu[v0:v0 + j.V], 'n_patches': j.n_patches, 'angle1': None, 'angle2': None}
+            if j.gt is not None:
+                g_ = torch.as_tensor(np.asarray(j.gt) if not torch.is_tensor(j.gt) else j.gt).to(device=dev, dtype=torch.float32).contiguous()
+                Nt = computer_face_normal(g_, j.fv)
+                out['angle1'] = network.error_n(j.Np, Nt)                 # device scalars: predict_batch reads them all at once
+                out['angle2'] = network.error_n(computer_face_normal(out['V_updated'], j.fv), Nt)
+            results[j.index] = out
+    finally:
+        for j in jobs:                        # nothing of a chain may still be running when its buffers and the mailbox go back
+            if getattr(j, 'gs', None) is not None:
+                j.gs.synchronize()
+
+
+def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data_type='Synthetic', patch_batch=12,
+                  split_group=4):
     """test_dual.py:90-148 (predict_dir) over a list of meshes with the SMALL ones -- at most ``sub_size`` faces, one
     network pass each in the reference -- going through the network and the vertex update several at a time, as one
     disjoint-union mesh of up to ``max_faces`` faces (in list order).  A single n = 32 mesh is a chain of
@@ -309,11 +471,20 @@ def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data
     fills those launches.  Components do not interact -- graph construction and the weights stay per mesh, the network's
     rows are independent per component (tests/test_gpu_model.py: test_full_size_properties), the vertex update walks each
     vertex's own faces -- so every mesh gets the bits ``predict_mesh`` gives it alone (tests/test_gpu_patches.py).  Meshes
-    above ``sub_size`` go through ``predict_mesh`` (patch split) one by one.
+    above ``sub_size`` take predict_mesh's patch-split steps ``split_group`` at a time (_predict_split_group: growth chains
+    side by side, network passes over the pooled patches ``patch_batch`` at a time, one vertex update); split_group = 1:
+    predict_mesh one by one.  The 29-mesh stand-in list (tools/test_list_probe.py, ms for the list): mesh by mesh 88.7;
+    small meshes as unions 73.0; + split groups of 2 / 5 patches per pass 64.9; groups of 4 / 12 patches per pass 46.8.
     meshes: list of (points, faces) or (points, faces, gt_points) -> list of predict_mesh's result dicts, in order."""
     dev = next(net.parameters()).device
     results = [None] * len(meshes)
     group, faces_in_group = [], 0
+    big = []
+
+    def flush_big():
+        if big:
+            _predict_split_group(net, list(big), results, sub_size, n_iter, data_type, patch_batch)
+            del big[:]
 
     def flush():
         if not group:
@@ -346,8 +517,8 @@ def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data
             if gt is not None:
                 g_ = torch.as_tensor(np.asarray(gt) if not torch.is_tensor(gt) else gt).to(device=dev, dtype=torch.float32).contiguous()
                 Nt = computer_face_normal(g_, fv)
-                out['angle1'] = float(network.error_n(out['Np'], Nt))
-                out['angle2'] = float(network.error_n(computer_face_normal(out['V_updated'], fv), Nt))
+                out['angle1'] = network.error_n(out['Np'], Nt)            # device scalars, read all at once at the end
+                out['angle2'] = network.error_n(computer_face_normal(out['V_updated'], fv), Nt)
             results[i] = out
         del group[:]
 
@@ -356,10 +527,18 @@ def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data
         pts = torch.as_tensor(np.asarray(m[0]) if not torch.is_tensor(m[0]) else m[0]).to(device=dev, dtype=torch.float32).contiguous()
         fv = torch.as_tensor(np.asarray(m[1]) if not torch.is_tensor(m[1]) else m[1]).to(device=dev, dtype=torch.int32).contiguous()
         F = fv.shape[0]
-        if F > sub_size or F == 0:              # the group stays open: results are placed by index
-            kw = {} if gt is None else {'gt_points': gt}
-            results[i] = predict_mesh(net, pts, fv, sub_size=sub_size, n_iter=n_iter, data_type=data_type,
-                                      patch_batch=patch_batch, distributed=False, **kw)
+        if F > sub_size or F == 0:              # the group of small meshes stays open: results are placed by index
+            if F == 0 or int(split_group) <= 1:
+                kw = {} if gt is None else {'gt_points': gt}
+                results[i] = predict_mesh(net, pts, fv, sub_size=sub_size, n_iter=n_iter, data_type=data_type,
+                                          patch_batch=patch_batch, distributed=False, **kw)
+                continue
+            lo, hi = L.read_i32(torch.cat([t.reshape(1) for t in torch.aminmax(fv)]))     # range-checked before any kernel
+            if lo < 0 or hi >= pts.shape[0]:
+                raise L.GeobiError('faces index vertices outside [0, %d)' % pts.shape[0])
+            big.append(_SplitJob(i, pts, fv, gt))
+            if len(big) >= int(split_group):
+                flush_big()
             continue
         if group and faces_in_group + F > max_faces:
             flush()
@@ -369,6 +548,13 @@ def predict_batch(net, meshes, max_faces=100000, sub_size=20000, n_iter=60, data
         group.append((i, pts, fv, dual, gt))
         faces_in_group += F
     flush()
+    flush_big()
+    # the angular errors of all meshes in ONE host read (predict_mesh reads two scalars per mesh)
+    slots = [(r, k) for r in results if r is not None for k in ('angle1', 'angle2') if torch.is_tensor(r[k])]
+    if slots:
+        vals = torch.stack([r[k].reshape(()) for r, k in slots]).tolist()
+        for (r, k), v in zip(slots, vals):
+            r[k] = v
     return results
 
 

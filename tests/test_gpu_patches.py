@@ -426,3 +426,29 @@ def test_predict_batch_equals_mesh_by_mesh(dev):
         for k in ('Vp', 'Np', 'V_updated'):
             assert torch.equal(w[k], g[k]), k
         assert w['angle1'] == g['angle1'] and w['angle2'] == g['angle2']
+
+
+@pytest.mark.parametrize('split_group,patch_batch', [(2, 5), (3, 2), (2, 1)])
+def test_predict_batch_split_meshes_in_groups(dev, split_group, patch_batch):
+    """patches.predict_batch with several meshes ABOVE the patch size: their growth chains run side by side, a network pass
+    takes patches of more than one mesh (patch_batch 2 cuts a mesh's patches across passes), one vertex update runs over the
+    union of the meshes -- and every mesh still gets predict_mesh's bits."""
+    from geobi_gnn_amd import network, meshgen, patches
+    torch.manual_seed(6)
+    net = network.DualGNN().to(dev).eval()
+    meshes = []
+    for i, n in enumerate((14, 9, 16, 13, 15, 8)):
+        noisy, clean, faces = meshgen.noisy_icosphere(n, (0.1, 0.2, 0.3)[i % 3], seed=700 + i)
+        meshes.append((torch.as_tensor(noisy, dtype=torch.float32, device=dev),
+                       torch.as_tensor(faces, dtype=torch.int32, device=dev),
+                       torch.as_tensor(clean, dtype=torch.float32, device=dev)))
+    with torch.no_grad():
+        want = [patches.predict_mesh(net, p, f, sub_size=3000, n_iter=10, gt_points=g, patch_batch=patch_batch) for p, f, g in meshes]
+        got = patches.predict_batch(net, meshes, max_faces=6000, sub_size=3000, n_iter=10, patch_batch=patch_batch,
+                                    split_group=split_group)
+    assert [w['n_patches'] for w in want] == [g['n_patches'] for g in got]
+    assert sum(w['n_patches'] > 1 for w in want) == 4
+    for w, g in zip(want, got):
+        for k in ('Vp', 'Np', 'V_updated'):
+            assert torch.equal(w[k], g[k]), k
+        assert w['angle1'] == g['angle1'] and w['angle2'] == g['angle2']
