@@ -1,6 +1,6 @@
 """Inference driver counterpart of /root/reference/code/test_dual.py:90-150 (predict_dir) on synthetic
 meshes: load a state dict written by tools/train_synthetic.py (reference key names), run every test mesh
-through patches.predict_mesh (device preprocessing, patch split at --sub_size, network, merge, 60-sweep
+through patches.predict_mesh (or, with --batched, patches.predict_batch; device preprocessing, patch split at --sub_size, network, merge, 60-sweep
 vertex update) and report the per-mesh angular errors and their face-count-weighted means exactly as the
 reference prints them.  The Synthetic test set is an external download, so the test list is SURVEY.md
 section 8d's stand-in: 29 noisy icospheres, n drawn from {16, 22, 32, 45} x 3 noise levels.
@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--n_meshes', type=int, default=29)
     ap.add_argument('--wei_param', type=int, default=2)
     ap.add_argument('--json', type=str, default='')
+    ap.add_argument('--batched', action='store_true', help='the whole list through patches.predict_batch (small meshes as unions, '
+                    'patch-split meshes in groups) instead of mesh by mesh: the same angles to the last bit, a list time instead of per-mesh times')
     opt = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
@@ -38,7 +40,20 @@ def main():
     freqs, sigmas = (16, 22, 32, 45), (0.1, 0.2, 0.3)
     err = np.zeros((3, opt.n_meshes))
     t_all = time.time()
-    for i in range(opt.n_meshes):
+    if opt.batched:
+        data = [meshgen.noisy_icosphere(freqs[i % 4], sigmas[i % 3], seed=100 + i) for i in range(opt.n_meshes)]
+        lst = [(torch.as_tensor(noisy, dtype=torch.float32, device=dev), torch.as_tensor(faces, dtype=torch.int32, device=dev),
+                torch.as_tensor(clean, dtype=torch.float32, device=dev)) for noisy, clean, faces in data]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        res = patches.predict_batch(net, lst, sub_size=opt.sub_size, n_iter=60)
+        torch.cuda.synchronize()
+        print('predict_batch: %d meshes in %.4f s' % (opt.n_meshes, time.time() - t0), flush=True)
+        for i, (r, (_, _, faces)) in enumerate(zip(res, data)):
+            err[:, i] = faces.shape[0], r['angle1'], r['angle2']
+            print("angle1: %9.6f,  angle2: %9.6f,  faces: %6d,  patches: %2d,  'ico%d_n%d'"
+                  % (r['angle1'], r['angle2'], faces.shape[0], r['n_patches'], freqs[i % 4], 1 + i % 3), flush=True)
+    for i in range(0 if opt.batched else opt.n_meshes):
         n, sg = freqs[i % 4], sigmas[i % 3]
         noisy, clean, faces = meshgen.noisy_icosphere(n, sg, seed=100 + i)
         t0 = time.time()
