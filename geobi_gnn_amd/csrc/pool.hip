@@ -140,41 +140,13 @@ __device__ __forceinline__ bool edge_better(float w1, int a1, int b1, float w2, 
 //   C: the neighbours' states and proposals    D: the proposals of the neighbours' targets
 // -- speculatively (a node that turns out to be decided has loaded a few words too many), instead of walking the
 // neighbours one by one with four dependent loads each.
-// Rounds that have nothing left to do.  A call launches a fixed number of rounds (eight; the host cannot know how many a
-// graph needs without reading something back) and mesh graphs converge in six or seven: the surplus rounds used to walk
-// every node through two load steps to find it decided (5.2 us each, 8-16 of them per training step).  Round r - 1 now
-// leaves conv[r] = 1 when any node made a proposal; a round that finds its word 0 returns at once -- nothing can be
-// proposed or matched any more, and the singletons it would have closed are closed by the commit kernel, which picks the
-// proposal buffer of the last round that DID run (match_final_props).  The first kRoundsAlways rounds never exit (their
-// flags would be thousands of stores to one word) and leave their successors' words alone: they are preset.
-constexpr int kRoundsAlways = 4;
-constexpr int kConvWords = 256;
-struct MatchConv {
-  int* conv;        // kConvWords words, or nullptr: every round runs
-  int round;        // this launch's round within the call (commit kernels: the number of rounds launched)
-};
-__device__ __forceinline__ const int* match_final_props(const int* prop0, const int* prop1, MatchConv mc) {
-  // round r writes prop1 when r is even, prop0 when it is odd (launch_match_rounds swaps after every round)
-  int last = mc.round - 1;
-  if (mc.conv != nullptr)
-    for (int r = kRoundsAlways; r < mc.round; ++r)
-      if (mc.conv[r] == 0) { last = r - 1; break; }
-  return (last & 1) ? prop0 : prop1;
-}
-
 template <int FIRST>
 __global__ __launch_bounds__(256) void match_round_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                    const float* __restrict__ w, const int* __restrict__ prop_prev, int N,
-                                   int* __restrict__ cluster, int* __restrict__ prop_next, int* __restrict__ status,
-                                   MatchConv mc) {
+                                   int* __restrict__ cluster, int* __restrict__ prop_next, int* __restrict__ status) {
   constexpr int MB = 4;                  // neighbours per batch (8 and 4 measure alike, 16 is slower)
   int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (FIRST != 0 && u == 0) {
-    *status = 0;
-    if (mc.conv != nullptr)
-      for (int i = kRoundsAlways; i < kConvWords; ++i) mc.conv[i] = 0;     // the first round of a call: nothing flagged yet
-  }
-  if (FIRST == 0 && mc.conv != nullptr && mc.round >= kRoundsAlways && mc.conv[mc.round] == 0) return;
+  if (FIRST != 0 && u == 0) *status = 0;
   if (u >= N) return;
   // ---- step A
   const int rs = rowptr[u], re = rowptr[u + 1];
@@ -245,9 +217,6 @@ __global__ __launch_bounds__(256) void match_round_kernel(const int* __restrict_
     }
   }
   prop_next[u] = best;
-  // somebody still proposes: the next round has work (only rounds that may be skipped are told; few proposers are left
-  // by then, and the lanes of a wave store to the one word together)
-  if (best >= 0 && mc.conv != nullptr && mc.round + 1 >= kRoundsAlways && mc.round + 1 < kConvWords) mc.conv[mc.round + 1] = 1;
 }
 
 // State of a node between calls (`cluster` of the launchers): -1 undecided, u closed as a singleton,
@@ -256,10 +225,9 @@ __global__ __launch_bounds__(256) void match_round_kernel(const int* __restrict_
 // commit of the last round + count of nodes that are still undecided; `final` (optional) receives the
 // clustering with the undecided nodes closed as singletons; flag / sz (optional, both or neither):
 // flag[u] = u is the representative (smaller member) of its cluster, sz[u] = its cluster size (0 for non-reps)
-__global__ void match_commit_kernel(const int* __restrict__ prop0, const int* __restrict__ prop1, MatchConv mc, int N,
-                                    int* __restrict__ cluster, int* __restrict__ remaining, int* __restrict__ final,
-                                    int* __restrict__ flag, int* __restrict__ sz) {
-  const int* __restrict__ prop = match_final_props(prop0, prop1, mc);
+__global__ void match_commit_kernel(const int* __restrict__ prop, int N, int* __restrict__ cluster,
+                                    int* __restrict__ remaining, int* __restrict__ final, int* __restrict__ flag,
+                                    int* __restrict__ sz) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u == 0 && flag) { flag[N] = 0; sz[N] = 0; }      // scan tails
   if (u >= N) return;
@@ -329,14 +297,12 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* s_wave, int&
   return off + inc - v;
 }
 
-__global__ __launch_bounds__(256) void match_commit_scan_kernel(const int* __restrict__ prop0,
-                                                                const int* __restrict__ prop1, MatchConv mc, int N,
+__global__ __launch_bounds__(256) void match_commit_scan_kernel(const int* __restrict__ prop, int N,
                                                                 int* __restrict__ cluster, int* __restrict__ remaining,
                                                                 int* __restrict__ final, int* __restrict__ lrank,
                                                                 int* __restrict__ loffs, int* __restrict__ bt_rank,
                                                                 int* __restrict__ bt_offs) {
   __shared__ int s_wave[4];
-  const int* __restrict__ prop = match_final_props(prop0, prop1, mc);
   const int u = blockIdx.x * 256 + threadIdx.x;
   int rep = 0, size = 0;
   if (u < N) {
@@ -1236,37 +1202,25 @@ int expand_rowptr(const int32_t* rowptr, int64_t N, int32_t* row, hipStream_t s)
 static int g_round_cap = 0;
 void set_match_round_cap(int cap) { g_round_cap = cap > 0 ? cap : 0; }
 
-// GEOBI_MATCH_EARLY_EXIT=0: every launched round walks its nodes (same-box A/B; the matching is the same either way)
-static bool match_early_exit() {
-  static const bool on = [] { const char* f = getenv("GEOBI_MATCH_EARLY_EXIT"); return !f || atoi(f) != 0; }();
-  return on;
-}
-
-// -> what the commit kernel needs to find the last round's proposals: the rounds launched and the flag words (null: all ran)
-static MatchConv launch_match_rounds(const int32_t* rowptr, const int32_t* col, const float* w, int N, int rounds, int init,
-                                     int32_t* cluster, int32_t* status, int* prop0, int* prop1, int* conv, hipStream_t s) {
+static void launch_match_rounds(const int32_t* rowptr, const int32_t* col, const float* w, int N, int rounds, int init,
+                                int32_t* cluster, int32_t* status, int*& pp, int*& pn, hipStream_t s) {
   const int blocks = cdiv(N, 256);
   if (g_round_cap > 0) {
     const int64_t capped = (int64_t)g_round_cap * (rounds > 8 ? rounds / 8 : 1);
     if (capped < rounds) rounds = (int)capped;
   }
-  if (!match_early_exit() || rounds > kConvWords) conv = nullptr;
-  int* pp = prop0;
-  int* pn = prop1;
   for (int r = 0; r < rounds; ++r) {
-    const MatchConv mc{conv, r};
     if (r > 0)
-      match_round_kernel<0><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status, mc);
+      match_round_kernel<0><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
     else if (init)
-      match_round_kernel<1><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status, mc);
+      match_round_kernel<1><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
     else
-      match_round_kernel<2><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status, mc);
+      match_round_kernel<2><<<blocks, 256, 0, s>>>(rowptr, col, w, pp, N, cluster, pn, status);
     int* t = pp; pp = pn; pn = t;
   }
-  return MatchConv{conv, rounds};
 }
 
-size_t match_ws_bytes(int64_t N) { return 2 * align_up((size_t)N * sizeof(int)) + align_up(kConvWords * sizeof(int)) + 1024; }
+size_t match_ws_bytes(int64_t N) { return 2 * align_up((size_t)N * sizeof(int)) + 1024; }
 
 // Runs `rounds` proposal rounds.  init != 0 starts from scratch, init == 0 continues from the state
 // in `cluster` (entries < 0 = undecided).  `status[0]` receives the number of nodes still undecided
@@ -1279,11 +1233,12 @@ int match_heavy_edge(const int32_t* rowptr, const int32_t* col, const float* w, 
   Arena a(ws, ws_bytes);
   int* prop0 = a.take<int>(N);
   int* prop1 = a.take<int>(N);
-  int* conv = a.take<int>(kConvWords);
   GEOBI_REQUIRE(a.ok() && prop0, "match: workspace too small");
   int blocks = cdiv(N, 256);
-  const MatchConv mc = launch_match_rounds(rowptr, col, w, (int)N, rounds, init, cluster, status, prop0, prop1, conv, s);
-  match_commit_kernel<<<blocks, 256, 0, s>>>(prop0, prop1, mc, (int)N, cluster, status, cluster_final, nullptr, nullptr);
+  int* pp = prop0;
+  int* pn = prop1;
+  launch_match_rounds(rowptr, col, w, (int)N, rounds, init, cluster, status, pp, pn, s);
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, cluster, status, cluster_final, nullptr, nullptr);
   GEOBI_LAUNCH_OK();
   return 0;
 }
@@ -1302,7 +1257,6 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
   Arena a(ws, ws_bytes);
   int* prop0 = a.take<int>(N);
   int* prop1 = a.take<int>(N);
-  int* conv = a.take<int>(kConvWords);
   int* flag = a.take<int>(N + 1);
   int* sz = a.take<int>(N + 1);
   int* rank = a.take<int>(N + 1);
@@ -1312,13 +1266,15 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
   void* temp_b = a.take<char>(tb);
   GEOBI_REQUIRE(a.ok() && prop0, "match_coarsen: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const int blocks = cdiv(N, 256);
-  const MatchConv mc = launch_match_rounds(rowptr, col, w, (int)N, rounds, init, state, counters, prop0, prop1, conv, s);
+  int* pp = prop0;
+  int* pn = prop1;
+  launch_match_rounds(rowptr, col, w, (int)N, rounds, init, state, counters, pp, pn, s);
   static const bool scan_free = [] { const char* f = getenv("GEOBI_MATCH_SCANFREE"); return !f || atoi(f) != 0; }();   // A/B knob
   if (scan_free && blocks <= kMaxScanBlocks) {
     // scan-free pair: block-local prefixes in the commit kernel, block totals folded by the list kernel
     int* bt_rank = rank;                 // rank / offs are free in this variant: reuse them for the block totals
     int* bt_offs = offs;
-    match_commit_scan_kernel<<<blocks, 256, 0, s>>>(prop0, prop1, mc, (int)N, state, counters, cluster_final, flag, sz, bt_rank, bt_offs);
+    match_commit_scan_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz, bt_rank, bt_offs);
     GEOBI_LAUNCH_OK();
     match_lists_scan_kernel<<<blocks, 256, 0, s>>>(state, cluster_final, flag, sz, bt_rank, bt_offs, blocks, (int)N, cnew,
                                                    counters + 1, segptr, members, rowptr, (int4*)rowinfo_out);
@@ -1327,7 +1283,7 @@ int match_coarsen(const int32_t* rowptr, const int32_t* col, const float* w, int
     return 0;
   }
   if (rowinfo_made) *rowinfo_made = false;
-  match_commit_kernel<<<blocks, 256, 0, s>>>(prop0, prop1, mc, (int)N, state, counters, cluster_final, flag, sz);
+  match_commit_kernel<<<blocks, 256, 0, s>>>(pp, (int)N, state, counters, cluster_final, flag, sz);
   GEOBI_LAUNCH_OK();
   if (N + 1 <= kSmallScan) {
     small_exclusive_scan2_kernel<<<1, 1024, 0, s>>>(flag, sz, rank, offs, N + 1);
