@@ -452,3 +452,25 @@ def test_predict_batch_split_meshes_in_groups(dev, split_group, patch_batch):
         for k in ('Vp', 'Np', 'V_updated'):
             assert torch.equal(w[k], g[k]), k
         assert w['angle1'] == g['angle1'] and w['angle2'] == g['angle2']
+
+
+def test_predict_batch_edge_cases(dev):
+    """An empty list, meshes without ground truth (no angles, no host read for them), a single mesh, a group cut by
+    max_faces smaller than any mesh (every small mesh then goes alone) and numpy inputs."""
+    from geobi_gnn_amd import network, meshgen, patches
+    torch.manual_seed(7)
+    net = network.DualGNN().to(dev).eval()
+    assert patches.predict_batch(net, []) == []
+    raw = [meshgen.noisy_icosphere(n, 0.2, seed=800 + i) for i, n in enumerate((8, 9, 10))]
+    with torch.no_grad():
+        want = [patches.predict_mesh(net, noisy, faces, sub_size=3000, n_iter=5) for noisy, _, faces in raw]
+        got = patches.predict_batch(net, [(noisy, faces) for noisy, _, faces in raw], sub_size=3000, n_iter=5)     # numpy in
+        alone = patches.predict_batch(net, [(noisy, faces) for noisy, _, faces in raw], max_faces=1, sub_size=3000, n_iter=5)
+    for w, g, a in zip(want, got, alone):
+        assert g['angle1'] is None and g['angle2'] is None and g['n_patches'] == 1
+        for k in ('Vp', 'Np', 'V_updated'):
+            assert torch.equal(w[k], g[k]) and torch.equal(w[k], a[k]), k
+    bad = (raw[0][0], raw[0][2].copy())
+    bad[1][0, 0] = 10 ** 6
+    with pytest.raises(Exception):
+        patches.predict_batch(net, [bad], sub_size=3000, n_iter=5)
