@@ -139,15 +139,6 @@ def measure_roofline(net, bucket, opt, dv, df, steps=6):
             if best is None or ms.value > best['ms']:
                 best = {'cin': cin, 'cout': cout, 'launches': n.value, 'ms': ms.value, 'bytes': by.value}
     lib.geobi_prof_enable(0)
-    # What a bracketing event pair adds to a launch's duration (the end event is a packet of its own behind the kernel; the
-    # start event's timestamp precedes the kernel's dispatch): an EMPTY pair on the same stream, measured here, median of 64.
-    # rocprofv3 times the kernel alone; raw event time minus this overhead is what must agree with its average.
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for a, b in pairs:
-        a.record(); b.record()
-    torch.cuda.synchronize()
-    overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[32]
-    net_ms = max(best['ms'] - overhead_ms * best['launches'], 0.5 * best['ms'])
     ach = best['bytes'] / (best['ms'] * 1e-3) / 1e9
     lc = best['cin'] if best['cin'] in (6, 12) else 0
     rows = 32 if os.environ.get('GEOBI_TILE16', '1') == '0' else 16
@@ -179,13 +170,9 @@ def measure_roofline(net, bucket, opt, dv, df, steps=6):
                       'note': 'node transform (matrix cores) + aggregation (packed FMAs) against the one fp32 ceiling of a '
                               'SIMD: the two do not overlap on gfx950 (profiles/r03_overlap_probe.txt)'},
         'launches': best['launches'], 'avg_us': round(avg_us, 2),
-        # achieved / frac above are from the RAW event brackets (they include the bracket's own packets: never flattering);
-        # the same minus an empty pair's duration brackets the rocprofv3 average of the kernel from the other side
-        # (one box: raw 49.4 / 47.8 us, minus overhead 44.7 / 43.1 us, rocprofv3 45.4 us)
-        'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
-        'avg_us_minus_event_overhead': round(net_ms * 1e3 / best['launches'], 2),
-        'frac_minus_event_overhead': round(best['bytes'] / (net_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-
+        'timing': 'HIP events bound to each launch of the kernel (hipExtLaunchKernelGGL start / stop events on its stream): the '
+                  'dispatch\'s own execution time, what rocprofv3 reports for it; a pair of hipEventRecord packets around a launch '
+                  'reads ~4.7 us more (rounds 1-3 and the first sets of round 4)',
         'alg_bytes_per_launch': round(best['bytes'] / best['launches']),
         'all_instantiations': {'launches': total['launches'],
                                'achieved': round(total['bytes'] / (total['ms'] * 1e-3) / 1e9, 1),

@@ -30,6 +30,7 @@ struct ProfRec {
   int tag;
   hipStream_t stream = nullptr;
   bool closed = false;
+  bool bound = false;      // events bound to a kernel's dispatch by the extended launch (no hipEventRecord)
 };
 static std::atomic<int> g_prof_kernel{PROF_NONE};
 static std::mutex g_prof_mu;             // the record list is shared by the host threads of a concurrent step
@@ -61,14 +62,47 @@ void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag) {
   g_prof.push_back(r);
 }
 
+static thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};      // handed from prof_begin_launch to the launch site
+
+void prof_begin_launch(int kernel, hipStream_t s, double alg_bytes, int tag) {
+  if (kernel != g_prof_kernel.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.a = get_event();
+  r.b = get_event();
+  r.bytes = alg_bytes;
+  r.tag = tag;
+  if (!r.a || !r.b) return;
+  r.stream = s;
+  g_launch_ev[0] = r.a;
+  g_launch_ev[1] = r.b;
+  r.bound = true;
+  g_prof.push_back(r);
+}
+
+bool prof_take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (g_launch_ev[0] == nullptr) return false;
+  *start = g_launch_ev[0];
+  *stop = g_launch_ev[1];
+  g_launch_ev[0] = g_launch_ev[1] = nullptr;
+  return true;
+}
+
 void prof_end(int kernel, hipStream_t s) {
   if (kernel != g_prof_kernel.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_launch_ev[0] != nullptr) {
+    // prof_begin_launch's events were not taken (a launch path without the extended launch): bracket nothing, drop the record
+    g_launch_ev[0] = g_launch_ev[1] = nullptr;
+    for (size_t i = g_prof.size(); i-- > 0;)
+      if (g_prof[i].stream == s && !g_prof[i].closed) { g_prof.erase(g_prof.begin() + (long)i); break; }
+    return;
+  }
   // the most recent open record of THIS stream (another thread's record may sit behind it)
   for (size_t i = g_prof.size(); i-- > 0;) {
     if (g_prof[i].stream == s && !g_prof[i].closed) {
       g_prof[i].closed = true;
-      (void)hipEventRecord(g_prof[i].b, s);
+      if (!g_prof[i].bound) (void)hipEventRecord(g_prof[i].b, s);
       return;
     }
   }

@@ -54,6 +54,12 @@ struct Arena {
 enum ProfKernel { PROF_NONE = 0, PROF_AGG_FWD = 1, PROF_AGG_BWD = 2, PROF_ROWPASS = 3, PROF_GEMM = 4 };
 void prof_begin(int kernel, hipStream_t s, double alg_bytes, int tag);
 void prof_end(int kernel, hipStream_t s);
+// The same bracket for ONE kernel launched through hipExtLaunchKernelGGL: the two events are bound to the kernel's own
+// dispatch (their elapsed time is the kernel's execution time, as a tracer reports it -- a pair of hipEventRecord packets
+// around a launch adds ~4.7 us of its own).  prof_begin_launch hands the events to the launch site of this host thread,
+// which takes them with prof_take_launch_events (false: not profiling, launch as usual).
+void prof_begin_launch(int kernel, hipStream_t s, double alg_bytes, int tag);
+bool prof_take_launch_events(hipEvent_t* start, hipEvent_t* stop);
 
 // ---- side stream for work that is off the critical path of a backward call (weight gradients)
 struct Fork {

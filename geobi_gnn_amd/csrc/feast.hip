@@ -723,7 +723,7 @@ int feast_fwd(const float* xa, const float* xb, int Ca, int Cb, int64_t N, int64
     }
     const int LCf = edge_logit_channels(Cin, Cb);
     if (LCf == 0) GEOBI_TRY(launch_logits(Cin, xa, xb ? xb : xa, Cb ? Ca : Cin, u_w, (int)N, p, s));
-    prof_begin(PROF_AGG_FWD, s, feast_fused_bytes(N, Ecap, Cin, Cout), Cin * 1000 + Cout);
+    prof_begin_launch(PROF_AGG_FWD, s, feast_fused_bytes(N, Ecap, Cin, Cout), Cin * 1000 + Cout);   // ONE launch: feast_fused_kernel
     int rcf = feast_fused_fwd(xa, xb ? xb : xa, Cb ? Ca : Cin, Cin, p, cvec, rowptr_in, col_in, (int)N, LCf, u_w, bf,
                               Cout, bias, slope, out, s);
     prof_end(PROF_AGG_FWD, s);
