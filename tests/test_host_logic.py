@@ -614,3 +614,18 @@ def test_tensorboard_event_writer_round_trip(tmp_path):
     bad.write_bytes(bytes(broken))
     with pytest.raises(ValueError):
         T.read_scalars(str(bad))
+
+
+def test_learned_arena_size_is_monotone_and_quantised():
+    """executor._learned_size: what later training passes on a level-0 shape allocate.  Needs that differ by a fraction of a
+    percent from pass to pass (other meshes of the same shape) must map to ONE size -- a size that followed every pass made
+    the block allocator hand out a fresh multi-GB block whenever the request grew past the cached one."""
+    from geobi_gnn_amd import executor
+    table, key = {}, (1, 2, 3, 4)
+    q = 64 << 20
+    sizes = [executor._learned_size(table, key, used) for used in (2674517504, 2675022592, 2674494720, 2673000000)]
+    assert len(set(sizes)) == 1 and sizes[0] % q == 0 and sizes[0] >= int(1.05 * 2675022592)
+    grown = executor._learned_size(table, key, 3 * 2674517504)
+    assert grown > sizes[0] and grown % q == 0
+    assert executor._learned_size(table, key, 1000) == grown                  # never shrinks
+    assert executor._learned_size({}, key, 0) == q                            # a floor of one quantum
