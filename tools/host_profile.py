@@ -6,12 +6,13 @@ import bench
 from geobi_gnn_amd import network
 from geobi_gnn_amd.parallel import FlatParameters
 dev = torch.device('cuda:0')
-freq = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+freq = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 torch.manual_seed(0)
 net = network.DualGNN().to(dev)
 flat = FlatParameters(net)
-opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=True)
-dv, df, edges = bench.make_batch(0, dev, freq)
+from geobi_gnn_amd.train_util import FlatAdam
+opt = FlatAdam(flat.parameters(), lr=1e-3)
+dv, df, edges, _ = bench.make_batch(0, dev, freq)
 for _ in range(5):
     bench.train_step(net, flat.bucket, opt, dv, df)
 torch.cuda.synchronize()
