@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void feast_logits_kernel(const float* __restri
 #pragma unroll
   for (int h = 0; h < H; ++h) acc[h] = 0.f;
   const int Cb = C - Ca;
-  if constexpr ((C & 3) == 0) {
+  // 16-B pieces only when neither input part cuts one (a 12-channel row split 6 | 6 used to be read as three float4 from
+  // the first part: found by tools/fuzz_kernels.py, no layer of the network has that shape)
+  if ((C & 3) == 0 && (Ca & 3) == 0) {
     for (int k = 0; k < C; k += 4) {
       const float* src = (k < Ca) ? xa + (size_t)n * Ca + k : xb + (size_t)n * Cb + (k - Ca);
       float4 t = *reinterpret_cast<const float4*>(src);

@@ -158,7 +158,8 @@ def _run_feast_impl(dev, Cin, Cout, ei, n, slope, split, seed, xscale, x):
                                                   (64, 128, 0.2, False), (128, 128, 0.2, False),
                                                   (128, 64, 1.0, False), (128, 64, 0.2, True),
                                                   (64, 32, 1.0, False), (64, 32, 0.2, True),
-                                                  (6, 64, 0.2, True), (12, 128, 1.0, False), (32, 32, 0.2, False)])
+                                                  (6, 64, 0.2, True), (12, 128, 1.0, False), (32, 32, 0.2, False),
+                                                  (12, 32, 0.2, True), (12, 128, 1.0, True)])     # 6 | 6: parts that cut a 16-B piece
 def test_feast_conv_random_graph(dev, Cin, Cout, slope, split, fused):
     n = 700          # 21 full tiles of 32 nodes + a ragged one
     ei = _sym_graph(n, 2500, seed=Cin + Cout)
