@@ -78,8 +78,9 @@ def ring_graph(kind, faces, rowptr, lst, num_nodes):
            ws.numel(), L.stream())
     E = L.read_i32(rp[n:n + 1], 1)[0]                       # one host read per graph (sizes the column array)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
-    L.call('geobi_ring_graph_fill', kind, L.ptr(faces), L.ptr(rowptr), L.ptr(lst), n, L.ptr(rp), L.ptr(col),
-           L.stream())
+    if E > 0:         # a graph without edges (the facet graph of a one-face patch: found by tools/fuzz_mesh.py) has nothing to fill
+        L.call('geobi_ring_graph_fill', kind, L.ptr(faces), L.ptr(rowptr), L.ptr(lst), n, L.ptr(rp), L.ptr(col),
+               L.stream())
     g = Graph(n, dev)
     g.rowptr_out, g.col_out, g.E = rp, col, E
     g.symmetric = True                                      # sharing a face / a vertex is a symmetric relation
@@ -183,7 +184,8 @@ def build_dual_data(points_noisy, faces, points_gt=None, name='mesh', data_type=
 
     def finish_graph(kind, n, rp, E):
         col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E]
-        L.call('geobi_ring_graph_fill', kind, L.ptr(fv), L.ptr(rowptr_vf), L.ptr(lst), n, L.ptr(rp), L.ptr(col), L.stream())
+        if E > 0:     # (a one-face patch has a facet graph without edges)
+            L.call('geobi_ring_graph_fill', kind, L.ptr(fv), L.ptr(rowptr_vf), L.ptr(lst), n, L.ptr(rp), L.ptr(col), L.stream())
         g = Graph(n, dev)
         g.rowptr_out, g.col_out, g.E = rp, col, E
         g.symmetric = True                                  # sharing a face / a vertex is a symmetric relation

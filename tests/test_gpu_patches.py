@@ -474,3 +474,24 @@ def test_predict_batch_edge_cases(dev):
     bad[1][0, 0] = 10 ** 6
     with pytest.raises(Exception):
         patches.predict_batch(net, [bad], sub_size=3000, n_iter=5)
+
+
+def test_one_face_patch(dev):
+    """A connected component of ONE face becomes a patch of its own (the growth stops when a component is exhausted): its
+    facet graph has no edges.  The graph fill used to be called with an empty column array and refused it
+    (tools/fuzz_mesh.py found it on icospheres with half of their faces removed)."""
+    from geobi_gnn_amd import network, meshgen, patches
+    noisy, _, faces = meshgen.noisy_icosphere(6, 0.2, seed=3)
+    V = noisy.shape[0]
+    lone = np.array([[10.0, 10.0, 10.0], [10.5, 10.0, 10.0], [10.0, 10.5, 10.1]], dtype=noisy.dtype)
+    pts = np.concatenate([noisy, lone], 0)
+    fcs = np.concatenate([faces, [[V, V + 1, V + 2]]], 0)
+    torch.manual_seed(2)
+    net = network.DualGNN().to(dev).eval()
+    with torch.no_grad():
+        r = patches.predict_mesh(net, pts, fcs, sub_size=300, n_iter=5)
+        alone = patches.predict_mesh(net, lone, np.array([[0, 1, 2]]), sub_size=300, n_iter=5)
+    assert r['n_patches'] >= 3
+    for out in (r, alone):
+        assert bool(torch.isfinite(out['Vp']).all() and torch.isfinite(out['Np']).all() and torch.isfinite(out['V_updated']).all())
+        assert bool(((out['Np'].norm(dim=1) - 1).abs() < 1e-4).all())
