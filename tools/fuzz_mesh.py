@@ -64,6 +64,32 @@ while time.time() < t_end:
     except Exception as ex:                                  # noqa: BLE001
         fails.append(('inference raised', tag, sub, repr(ex)[:300]))
     count['inference'] += 1
+# ---- lists of irregular meshes through predict_batch against mesh-by-mesh inference, bit for bit
+t_end = time.time() + budget / 3
+count['batch'] = 0
+while time.time() < t_end:
+    lst = []
+    for _ in range(rng.choice([2, 3, 5])):
+        n = rng.choice([3, 5, 8, 12]); drop = rng.choice([0.0, 0.1, 0.3]); seed = rng.randrange(100000)
+        noisy, clean, faces = meshgen.noisy_icosphere(n, 0.2, seed)
+        faces = np.ascontiguousarray(faces[np.random.default_rng(seed).random(faces.shape[0]) >= drop])
+        if faces.shape[0] >= 4:
+            lst.append((torch.as_tensor(noisy, dtype=torch.float32, device=dev), torch.as_tensor(faces, dtype=torch.int32, device=dev),
+                        torch.as_tensor(clean, dtype=torch.float32, device=dev)))
+    sub = rng.choice([150, 600, 3000]); pb = rng.choice([1, 3, 12]); sg = rng.choice([1, 2, 4]); mf = rng.choice([500, 3000, 100000])
+    try:
+        with torch.no_grad():
+            want = [patches.predict_mesh(net, p, f, sub_size=sub, n_iter=5, gt_points=g, patch_batch=pb) for p, f, g in lst]
+            got = patches.predict_batch(net, lst, max_faces=mf, sub_size=sub, n_iter=5, patch_batch=pb, split_group=sg)
+        for w, g in zip(want, got):
+            same = all(torch.equal(torch.nan_to_num(w[k]), torch.nan_to_num(g[k])) for k in ('Vp', 'Np', 'V_updated'))
+            same = same and w['n_patches'] == g['n_patches'] and (w['angle1'] == g['angle1'] or (w['angle1'] != w['angle1'] and g['angle1'] != g['angle1']))
+            if not same:
+                fails.append(('batch', [int(f.shape[0]) for _, f, _ in lst], sub, pb, sg, mf))
+                break
+    except Exception as ex:                                  # noqa: BLE001
+        fails.append(('batch raised', [int(f.shape[0]) for _, f, _ in lst], sub, pb, sg, mf, repr(ex)[:300]))
+    count['batch'] += 1
 print('cases', count, 'failures', len(fails))
 for f in fails[:12]:
     print('  FAIL', f)

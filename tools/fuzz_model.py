@@ -97,7 +97,14 @@ while time.time() < t_end:
     freqs = [rng.choice([2, 3, 4, 5, 6, 7, 9])] if rng.random() < 0.6 else [rng.choice([2, 3, 4, 5]) for _ in range(rng.choice([2, 3]))]
     sd = make_state_dict(R.DualGNN().state_dict(), seed % 97)
     net = M._hip_net(sd, dev)
-    pairs = [meshgen.synthetic_dual_data(fq, rng.choice([0.1, 0.2, 0.3]), seed=(seed + i) % 100000) for i, fq in enumerate(freqs)]
+    pairs = []
+    for i, fq in enumerate(freqs):
+        if fq >= 4 and rng.random() < 0.4:                   # an irregular mesh: holes, boundaries, vertices without faces
+            noisy, clean, faces = meshgen.noisy_icosphere(fq, rng.choice([0.1, 0.3]), (seed + i) % 100000)
+            faces = np.ascontiguousarray(faces[np.random.default_rng(seed + i).random(faces.shape[0]) >= rng.choice([0.05, 0.2])])
+            pairs.append(meshgen.build_dual_data(noisy, faces, clean, name='m'))
+        else:
+            pairs.append(meshgen.synthetic_dual_data(fq, rng.choice([0.1, 0.2, 0.3]), seed=(seed + i) % 100000))
     dv, df = pairs[0] if len(pairs) == 1 else union_batch(pairs)
     dvo = P.Data(dv.x.clone(), dv.edge_index.clone(), edge_weight=dv.edge_weight.clone(), y=dv.y.clone())
     dfo = P.Data(df.x.clone(), df.edge_index.clone(), edge_weight=df.edge_weight.clone(), y=df.y.clone(), fv_indices=df.fv_indices.clone())
